@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SEPAIHRD likelihood hot path on MI355X.
+
+A "step" is one pass of the hot path (theta -> ODE solve -> Poisson log-likelihood) over one
+batch of synthetic parameter draws that is already resident in HBM.  Default workload is
+BASELINE.json configs[1]: SEPAIHRD, 4 age groups, Dopri5 (abs=rel=1e-6), 400-day daily grid
+(t=-20..380, T=401), 4096 independent chains per GPU, fp64.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run, one rank per GPU (RCCL).  Chains are independent, so ranks shard the
+chains with no data-path collective ("scaling": "weak"); the only collective is the barrier /
+max-reduction of the elapsed time, plus the optional post-run all-gather of per-chain summaries
+(reported separately, outside the timed region).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 peak (public spec)
+LOG_FLOP_EQUIV = 20         # flop-equivalents per log
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU per step")
+    ap.add_argument("--solver", choices=["dopri5", "cashkarp"], default="dopri5")
+    ap.add_argument("--arith", choices=["strict", "fma"], default="strict")
+    ap.add_argument("--problem", default="synth_400d_n4.json")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
+    return ap.parse_args()
+
+
+def algorithmic_flops_per_eval(n, accepted_steps, t_obs):
+    rhs = 2 * n * n + 43 * n + 1
+    return accepted_steps * (6 * rhs + 59 * 11 * n) + rhs + 3 * t_obs * n * (LOG_FLOP_EQUIV + 4)
+
+
+def problem_bytes(pb):
+    """Shared read-only problem data read once per launch (amortised over the batch)."""
+    n, T = pb.n, pb.n_times
+    return 8 * (T + 3 * pb.n_obs * n + n * n + 11 * n + 10 * n + len(pb.beta_values) * 2 +
+                len(pb.kappa_values) * 2 + 3 * pb.n_params)
+
+
+def cpu_baseline(pb, theta, budget_s):
+    """Oracle (CPU restatement of the reference path, kind "port") on a bounded sample of the
+    same draws, OpenMP over chains on all host cores.  Checker only: never the measured path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    orc = oracle_py.Oracle(pb)
+    cores = oracle_py.load().oracle_num_threads()
+    probe = min(len(theta), 4 * cores)
+    t0 = time.perf_counter()
+    orc.eval_batch(theta[:probe], nthreads=cores)
+    t_probe = time.perf_counter() - t0
+    n_eval = int(max(probe, min(len(theta), budget_s / max(t_probe / probe, 1e-9))))
+    t0 = time.perf_counter()
+    orc.eval_batch(theta[:n_eval], nthreads=cores)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n1 = max(1, min(n_eval, int(2.0 / max(t_probe / probe * cores, 1e-9)) or 1))
+    orc.eval_batch(theta[:n1], nthreads=1)
+    dt1 = time.perf_counter() - t0
+    return {
+        "value": n_eval / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": f"{n_eval} of the same jittered draws, oracle/liboracle.so (g++ -O3, no -march=native, "
+                  f"no FMA), OpenMP over chains, {cores} threads; 1 thread: {n1 / dt1:.1f} evals/s",
+        "single_thread_value": n1 / dt1,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import mmid_amd_loader
+    mm = mmid_amd_loader.load()
+    from mmid_amd import draws
+
+    pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", args.problem))
+    pb.solver = mm.SOLVER_DOPRI5 if args.solver == "dopri5" else mm.SOLVER_CASH_KARP54
+    pb.arith = mm.ARITH_STRICT if args.arith == "strict" else mm.ARITH_FMA
+    pb.constraint_mode = mm.CONSTRAINT_REFLECT
+    B, K, W = args.chains, args.steps, args.warmup
+    P = pb.n_params
+
+    # synthetic draws: chain b of rank r in pool slot s owns mt19937(1 + (s*world + r)*B + b)
+    n_pool = min(max(K, 1), 4)
+    pools_host = [draws.jitter_draws(pb, 1 + (s * world + rank) * B, B) for s in range(n_pool)]
+    dev = torch.device("cuda", local_rank)
+    pools = [torch.from_numpy(p).to(dev) for p in pools_host]
+    d_ll = torch.empty(B, dtype=torch.float64, device=dev)
+    d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    d_acc = torch.empty(B, dtype=torch.int32, device=dev)
+    d_rej = torch.empty(B, dtype=torch.int32, device=dev)
+
+    hip = mm.HipObjective(pb, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        hip.eval_batch_device(pools[i % n_pool], d_ll, d_status=d_status, d_n_accept=d_acc, d_n_reject=d_rej,
+                              stream=stream.cuda_stream, B=B)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(K):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(K, 1)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed_max = float(el.item())
+
+    status = d_status.cpu().numpy()
+    acc = d_acc.cpu().numpy().astype(np.float64)
+    rej = d_rej.cpu().numpy().astype(np.float64)
+
+    allgather_ms = None
+    if args.allgather and world > 1:
+        # post-calibration ensemble summary record per chain: [P means | P variances |
+        # best logpost | accept count] -- here filled with the chain's theta and log-likelihood
+        rec = torch.zeros(B, 2 * P + 2, dtype=torch.float64, device=dev)
+        rec[:, :P] = pools[(K - 1) % n_pool]
+        rec[:, 2 * P] = d_ll
+        gathered = torch.empty(world * B, 2 * P + 2, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, rec)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, rec)
+        torch.cuda.synchronize(dev)
+        allgather_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        evals_total = world * B * K
+        value = evals_total / elapsed_max
+        info = hip.kernel_info()
+        bytes_eval = 8 * P + 16 + problem_bytes(pb) / B
+        bytes_launch = bytes_eval * B
+        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        flops_eval = algorithmic_flops_per_eval(pb.n, float(acc.mean()), pb.n_obs)
+        fp64_tflops = flops_eval * B / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        traffic_src = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_src):
+            try:
+                with open(traffic_src) as fh:
+                    tj = json.load(fh)
+                key = f"{args.solver}_{args.arith}_B{B}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ODE-solve+likelihood evals/sec (SEPAIHRD 4-age, 400d)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed_max / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: SEPAIHRD {pb.n} age groups, {args.solver}, "
+                            f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
+                "chains_per_gpu": B, "n_params": P, "abs_err": pb.abs_err, "rel_err": pb.rel_err,
+                "arith": args.arith, "draws": "reflect(base + sigma*N(0,1)), mt19937(1+chain), libstdc++ order",
+                "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "kernel": info["kernel_name"], "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_eval": bytes_eval,
+                "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d): see fp64_valu",
+                "fp64_valu": {"achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
+                              "algorithmic_flops_per_eval": flops_eval},
+            },
+            "kernel_info": {k: info[k] for k in ("lanes_per_chain", "chains_per_wave", "vgprs", "lds_bytes",
+                                                 "scratch_bytes", "max_blocks_per_cu", "num_cus",
+                                                 "device_name")},
+            "steps_per_eval": {"accepted_mean": float(acc.mean()), "rejected_mean": float(rej.mean()),
+                               "attempts_max": float((acc + rej).max())},
+            "status_counts": np.bincount(status, minlength=4).tolist(),
+        }
+        if allgather_ms is not None:
+            out["allgather_ms"] = allgather_ms
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pb, pools_host[0], args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,427 @@
+// csrc/sepaihrd_capi.cpp -- implementation of the C ABI declared in include/sepaihrd_hip.h.
+// Host side only: validates the problem, resolves the theta -> field map into slot tables,
+// uploads the problem to HBM once, and launches the HIP kernels.  There is no CPU
+// evaluation path in this library.
+#include "sepaihrd_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "sepaihrd_device.h"
+
+using namespace sepaihrd;
+
+struct sepaihrd_ctx {
+    int device = 0;
+    int solver = 0;
+    int arith = 0;
+    DevProblem dp{};
+    std::vector<void*> allocs;
+    // host copies needed by sepaihrd_apply_constraints
+    std::vector<double> lower, upper;
+    std::vector<uint8_t> has_bounds;
+    int n = 0, T = 0, P = 0;
+    std::string last_error;
+    // staging buffers for the host-pointer entry point (grown on demand)
+    size_t cap_B = 0;
+    bool cap_traj = false;
+    double* d_theta = nullptr;
+    double* d_loglik = nullptr;
+    int32_t* d_status = nullptr;
+    int32_t* d_nacc = nullptr;
+    int32_t* d_nrej = nullptr;
+    double* d_parts = nullptr;
+    double* d_traj = nullptr;
+    size_t cap_traj_elems = 0;
+};
+
+namespace {
+
+void set_err(char* err, int errlen, const std::string& msg) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
+}
+
+#define HIP_TRY(expr, ctx, fail)                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            fail;                                                                            \
+        }                                                                                    \
+    } while (0)
+
+template <class T>
+const T* upload(sepaihrd_ctx* ctx, const std::vector<T>& v, bool& ok) {
+    if (v.empty()) {
+        // keep a valid (1-element) allocation so kernels may form the pointer
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+        ctx->allocs.push_back(p);
+        return static_cast<const T*>(p);
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, v.size() * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+    ctx->allocs.push_back(p);
+    if (hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    return static_cast<const T*>(p);
+}
+
+// SEPAIHRDParameterManager.cpp:302-313
+double reflect_bound_host(double value, double minb, double maxb) {
+    if (minb >= maxb) return minb;
+    const double width = maxb - minb;
+    double y = std::fmod(value - minb, 2.0 * width);
+    if (y < 0) y += 2.0 * width;
+    if (y <= width) return minb + y;
+    return maxb - (y - width);
+}
+
+void free_staging(sepaihrd_ctx* c) {
+    void* ptrs[] = {c->d_theta, c->d_loglik, c->d_status, c->d_nacc, c->d_nrej, c->d_parts, c->d_traj};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_theta = c->d_loglik = c->d_parts = c->d_traj = nullptr;
+    c->d_status = c->d_nacc = c->d_nrej = nullptr;
+    c->cap_B = 0;
+    c->cap_traj_elems = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sepaihrd_abi_version(void) { return SEPAIHRD_ABI_VERSION; }
+
+sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err, int errlen) {
+    if (!pb) { set_err(err, errlen, "problem is NULL"); return nullptr; }
+    if (pb->abi_version != SEPAIHRD_ABI_VERSION) { set_err(err, errlen, "ABI version mismatch"); return nullptr; }
+    const int n = pb->n_age, T = pb->n_times, P = pb->n_params, nb = pb->n_beta, nk = pb->n_kappa;
+    if (n < 1 || n > SEPAIHRD_MAX_AGE_CLASSES) { set_err(err, errlen, "n_age out of range [1,64]"); return nullptr; }
+    if (lanes_per_chain(n) > 16) {
+        set_err(err, errlen, "n_age > 16 not built in this version"); return nullptr;
+    }
+    if (T < 1) { set_err(err, errlen, "n_times must be >= 1"); return nullptr; }
+    if (P < 1) { set_err(err, errlen, "n_params must be >= 1"); return nullptr; }
+    if (nk < 1 || nk > SEPAIHRD_MAX_SCHEDULE || nb < 0 || nb > SEPAIHRD_MAX_SCHEDULE) {
+        set_err(err, errlen, "schedule lengths out of range (n_kappa >= 1)"); return nullptr;
+    }
+    if (!pb->times || !pb->N || !pb->M || !pb->a || !pb->h_infec || !pb->p || !pb->h || !pb->icu ||
+        !pb->d_H || !pb->d_ICU || !pb->kappa_end_times || !pb->kappa_values || !pb->initial_state ||
+        !pb->param_field || !pb->param_index || (nb > 0 && (!pb->beta_end_times || !pb->beta_values)) ||
+        (pb->n_obs > 0 && (!pb->obs_H || !pb->obs_ICU || !pb->obs_D))) {
+        set_err(err, errlen, "a required array pointer is NULL"); return nullptr;
+    }
+    if (pb->solver != SEPAIHRD_SOLVER_DOPRI5 && pb->solver != SEPAIHRD_SOLVER_CASH_KARP54) {
+        set_err(err, errlen, "unknown solver"); return nullptr;
+    }
+    // Simulator::run grid validation (Simulator.cpp:78-88) and ctor checks (:15-44)
+    for (int i = 1; i < T; ++i)
+        if (!(pb->times[i] > pb->times[i - 1])) {
+            set_err(err, errlen, "time points must be strictly increasing"); return nullptr;
+        }
+    if (pb->abs_err < 0 || pb->rel_err < 0) { set_err(err, errlen, "negative error tolerance"); return nullptr; }
+    if (!(pb->dt_hint > 0)) { set_err(err, errlen, "dt_hint must be positive"); return nullptr; }
+    // schedule validation: PiecewiseConstantNpiStrategy ctor (PieceWiseConstantNPIStrategy.cpp:24-54),
+    // PiecewiseConstantParameterStrategy ctor (PiecewiseConstantParameterStrategy.cpp:22-34)
+    if (pb->kappa_end_times[0] < 0.0) { set_err(err, errlen, "kappa baseline end time must be non-negative"); return nullptr; }
+    for (int k = 1; k < nk; ++k)
+        if (!(pb->kappa_end_times[k] > pb->kappa_end_times[k - 1])) {
+            set_err(err, errlen, "kappa end times must be strictly increasing"); return nullptr;
+        }
+    for (int k = 1; k < nb; ++k)
+        if (!(pb->beta_end_times[k] > pb->beta_end_times[k - 1])) {
+            set_err(err, errlen, "beta end times must be strictly increasing"); return nullptr;
+        }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err(err, errlen, "no HIP device available (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) { set_err(err, errlen, "hipGetDevice failed"); return nullptr; }
+    }
+    if (device >= ndev) { set_err(err, errlen, "device index out of range"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return nullptr; }
+
+    auto* ctx = new sepaihrd_ctx();
+    ctx->device = device;
+    ctx->solver = pb->solver;
+    ctx->arith = pb->arith == SEPAIHRD_ARITH_FMA ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT;
+    ctx->n = n; ctx->T = T; ctx->P = P;
+
+    const int lpc = lanes_per_chain(n);
+    const int ns = SS_SCHEDULE0 + nb + nk;
+
+    // ---- slot tables: later theta entries overwrite earlier ones, as the reference's
+    //      sequential loop over names does (SEPAIHRDParameterManager.cpp:197-267)
+    std::vector<int32_t> src_scalar(ns, -1);
+    std::vector<double> base_scalar(ns, 0.0);
+    base_scalar[SS_BETA] = pb->beta; base_scalar[SS_THETA] = pb->theta; base_scalar[SS_SIGMA] = pb->sigma;
+    base_scalar[SS_GAMMA_P] = pb->gamma_p; base_scalar[SS_GAMMA_A] = pb->gamma_A;
+    base_scalar[SS_GAMMA_I] = pb->gamma_I; base_scalar[SS_GAMMA_H] = pb->gamma_H;
+    base_scalar[SS_GAMMA_ICU] = pb->gamma_ICU;
+    for (int i = 0; i < 8; ++i) base_scalar[SS_E0_MULT + i] = pb->multipliers[i];
+    base_scalar[SS_RUNUP_DAYS] = pb->runup_days; base_scalar[SS_SEED_EXPOSED] = pb->seed_exposed;
+    for (int k = 0; k < nb; ++k) base_scalar[SS_SCHEDULE0 + k] = pb->beta_values[k];
+    for (int k = 0; k < nk; ++k) base_scalar[SS_SCHEDULE0 + nb + k] = pb->kappa_values[k];
+
+    std::vector<int32_t> src_vec((size_t)VF_COUNT * lpc, -1);
+    std::vector<double> base_vec((size_t)VF_COUNT * lpc, 0.0);
+    const double* vec_base_ptr[VF_COUNT] = {pb->a, pb->h_infec, pb->p, pb->h, pb->icu, pb->d_H, pb->d_ICU,
+                                            pb->d_community};
+    for (int f = 0; f < VF_COUNT; ++f)
+        for (int i = 0; i < n; ++i) base_vec[(size_t)f * lpc + i] = vec_base_ptr[f] ? vec_base_ptr[f][i] : 0.0;
+
+    int kappa_calibrated = 0;
+    for (int p = 0; p < P; ++p) {
+        const int f = pb->param_field[p], idx = pb->param_index[p];
+        auto bad = [&](const char* what) {
+            set_err(err, errlen, std::string("param ") + std::to_string(p) + ": " + what);
+            delete ctx;
+            return static_cast<sepaihrd_ctx*>(nullptr);
+        };
+        if (f == SEPAIHRD_F_NONE) continue;
+        if (f >= SEPAIHRD_F_BETA && f <= SEPAIHRD_F_SEED_EXPOSED) {
+            src_scalar[f] = p;
+        } else if (f == SEPAIHRD_F_BETA_VALUE) {
+            if (idx < 0 || idx >= nb) return bad("beta index out of range");
+            src_scalar[SS_SCHEDULE0 + idx] = p;
+        } else if (f == SEPAIHRD_F_KAPPA_VALUE) {
+            if (idx < 1 || idx >= nk) return bad("kappa index out of range (index 0 is the fixed baseline)");
+            src_scalar[SS_SCHEDULE0 + nb + idx] = p;
+            kappa_calibrated = 1;
+        } else if (f >= SEPAIHRD_F_A && f <= SEPAIHRD_F_D_COMMUNITY) {
+            if (idx < 0 || idx >= n) return bad("age index out of range");
+            src_vec[(size_t)(f - SEPAIHRD_F_A) * lpc + idx] = p;
+        } else {
+            return bad("unknown field code");
+        }
+    }
+
+    // ---- padded per-age tables
+    std::vector<double> Npad(lpc, 0.0), fracpad(lpc, 0.0), Mrow((size_t)lpc * lpc, 0.0),
+        init((size_t)NUM_COMP * lpc, 0.0);
+    double total_pop = 0.0;
+    for (int i = 0; i < n; ++i) { Npad[i] = pb->N[i]; total_pop += pb->N[i]; }
+    if (total_pop > 0.0)  // SEPAIHRDObjectiveFunction.cpp:103-108
+        for (int i = 0; i < n; ++i) fracpad[i] = pb->N[i] / total_pop;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Mrow[(size_t)i * lpc + j] = pb->M[(size_t)j * n + i];
+    for (int c = 0; c < NUM_COMP; ++c)
+        for (int i = 0; i < n; ++i) init[(size_t)c * lpc + i] = pb->initial_state[(size_t)c * n + i];
+
+    int runup_offset = 0;  // SEPAIHRDObjectiveFunction.cpp:39-46
+    for (int i = 0; i < T; ++i)
+        if (pb->times[i] >= 0.0) { runup_offset = i; break; }
+    const int num_obs_points = T - runup_offset;
+    const int n_obs = pb->n_obs;
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> obs((size_t)3 * std::max(n_obs, 1) * lpc, qnan);
+    const double* obs_ptr[3] = {pb->obs_H, pb->obs_ICU, pb->obs_D};
+    for (int s = 0; s < 3; ++s)
+        for (int r = 0; r < n_obs; ++r)
+            for (int i = 0; i < n; ++i)
+                obs[((size_t)s * n_obs + r) * lpc + i] = obs_ptr[s][(size_t)r * n + i];
+
+    double max_gap = 0.0;
+    for (int i = 1; i < T; ++i) max_gap = std::max(max_gap, pb->times[i] - pb->times[i - 1]);
+
+    ctx->lower.assign(P, 0.0); ctx->upper.assign(P, 0.0); ctx->has_bounds.assign(P, 0);
+    std::vector<int32_t> hb(P, 0);
+    for (int p = 0; p < P; ++p) {
+        const bool has = pb->has_bounds ? pb->has_bounds[p] != 0 : (pb->lower && pb->upper);
+        ctx->has_bounds[p] = has ? 1 : 0;
+        hb[p] = has ? 1 : 0;
+        if (has) { ctx->lower[p] = pb->lower[p]; ctx->upper[p] = pb->upper[p]; }
+    }
+
+    DevProblem& d = ctx->dp;
+    d.n = n; d.lpc = lpc; d.T = T; d.n_obs = n_obs; d.runup_offset = runup_offset; d.nb = nb; d.nk = nk;
+    d.P = P; d.ns = ns;
+    d.constraint_mode = pb->constraint_mode == SEPAIHRD_CONSTRAINT_REFLECT ? 1 : 0;
+    d.kappa_calibrated = kappa_calibrated;
+    d.max_attempts = pb->max_attempts > 0 ? pb->max_attempts : 1000000;
+    d.obs_rows_match = (num_obs_points == n_obs) ? 1 : 0;
+    d.abs_tol = pb->abs_err; d.rel_tol = pb->rel_err; d.dt_hint = pb->dt_hint; d.max_gap = max_gap;
+
+    bool ok = true;
+    d.times = upload(ctx, std::vector<double>(pb->times, pb->times + T), ok);
+    d.obs = upload(ctx, obs, ok);
+    d.lower = upload(ctx, ctx->lower, ok);
+    d.upper = upload(ctx, ctx->upper, ok);
+    d.has_bounds = upload(ctx, hb, ok);
+    d.src_scalar = upload(ctx, src_scalar, ok);
+    d.base_scalar = upload(ctx, base_scalar, ok);
+    d.src_vec = upload(ctx, src_vec, ok);
+    d.base_vec = upload(ctx, base_vec, ok);
+    d.N = upload(ctx, Npad, ok);
+    d.age_fraction = upload(ctx, fracpad, ok);
+    d.Mrow = upload(ctx, Mrow, ok);
+    d.init_state = upload(ctx, init, ok);
+    d.beta_ends = upload(ctx, std::vector<double>(pb->beta_end_times, pb->beta_end_times + nb), ok);
+    d.kappa_ends = upload(ctx, std::vector<double>(pb->kappa_end_times, pb->kappa_end_times + nk), ok);
+    if (!ok) {
+        set_err(err, errlen, "device allocation / upload failed");
+        sepaihrd_destroy(ctx);
+        return nullptr;
+    }
+    if (eval_lds_bytes(d) > 64 * 1024) {
+        set_err(err, errlen, "n_params too large for the LDS staging buffer");
+        sepaihrd_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void sepaihrd_destroy(sepaihrd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_staging(ctx);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+}
+
+const char* sepaihrd_last_error(const sepaihrd_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "ctx is NULL"; }
+
+int sepaihrd_set_constraint_mode(sepaihrd_ctx* ctx, int mode) {
+    if (!ctx || (mode != SEPAIHRD_CONSTRAINT_CLAMP && mode != SEPAIHRD_CONSTRAINT_REFLECT))
+        return SEPAIHRD_E_INVALID_ARG;
+    ctx->dp.constraint_mode = mode;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_set_arith(sepaihrd_ctx* ctx, int arith) {
+    if (!ctx || (arith != SEPAIHRD_ARITH_STRICT && arith != SEPAIHRD_ARITH_FMA)) return SEPAIHRD_E_INVALID_ARG;
+    ctx->arith = arith;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, double* d_loglik,
+                               int32_t* d_status, int32_t* d_n_accept, int32_t* d_n_reject,
+                               double* d_ll_parts, double* d_traj, void* stream) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!d_theta || !d_loglik))) {
+        ctx->last_error = "eval_batch_device: NULL theta/loglik or negative B";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    if (B == 0) return SEPAIHRD_OK;
+    EvalOutputs out{d_loglik, d_status, d_n_accept, d_n_reject, d_ll_parts, d_traj};
+    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA
+                       ? launch_eval_fma(ctx->dp, ctx->solver, d_theta, B, out, stream)
+                       : launch_eval_strict(ctx->dp, ctx->solver, d_theta, B, out, stream);
+    if (rc != 0) {
+        ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
+        return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
+    }
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* loglik, int32_t* status,
+                        int32_t* n_accept, int32_t* n_reject, double* ll_parts, double* traj) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!theta || !loglik))) {
+        ctx->last_error = "eval_batch: NULL theta/loglik or negative B";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    if (B == 0) return SEPAIHRD_OK;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const size_t traj_elems = traj ? (size_t)B * ctx->T * NUM_COMP * ctx->n : 0;
+    if ((size_t)B > ctx->cap_B) {
+        const size_t keep_traj = ctx->cap_traj_elems;
+        double* keep = ctx->d_traj;
+        ctx->d_traj = nullptr;
+        free_staging(ctx);
+        ctx->d_traj = keep;
+        ctx->cap_traj_elems = keep_traj;
+        HIP_TRY(hipMalloc((void**)&ctx->d_theta, (size_t)B * ctx->P * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_loglik, (size_t)B * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_status, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_nacc, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_nrej, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_parts, (size_t)B * 3 * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        ctx->cap_B = (size_t)B;
+    }
+    if (traj_elems > ctx->cap_traj_elems) {
+        if (ctx->d_traj) (void)hipFree(ctx->d_traj);
+        ctx->d_traj = nullptr;
+        ctx->cap_traj_elems = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->d_traj, traj_elems * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        ctx->cap_traj_elems = traj_elems;
+    }
+    HIP_TRY(hipMemcpy(ctx->d_theta, theta, (size_t)B * ctx->P * sizeof(double), hipMemcpyHostToDevice), ctx,
+            return SEPAIHRD_E_HIP);
+    const int rc = sepaihrd_eval_batch_device(ctx, ctx->d_theta, B, ctx->d_loglik, ctx->d_status, ctx->d_nacc,
+                                              ctx->d_nrej, ctx->d_parts, traj ? ctx->d_traj : nullptr, nullptr);
+    if (rc != SEPAIHRD_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize(), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(loglik, ctx->d_loglik, (size_t)B * sizeof(double), hipMemcpyDeviceToHost), ctx,
+            return SEPAIHRD_E_HIP);
+    if (status)
+        HIP_TRY(hipMemcpy(status, ctx->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    if (n_accept)
+        HIP_TRY(hipMemcpy(n_accept, ctx->d_nacc, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    if (n_reject)
+        HIP_TRY(hipMemcpy(n_reject, ctx->d_nrej, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    if (ll_parts)
+        HIP_TRY(hipMemcpy(ll_parts, ctx->d_parts, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    if (traj)
+        HIP_TRY(hipMemcpy(traj, ctx->d_traj, traj_elems * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_apply_constraints(const sepaihrd_ctx* ctx, int mode, const double* in, int B, double* out) {
+    if (!ctx || !in || !out || B < 0) return SEPAIHRD_E_INVALID_ARG;
+    const int P = ctx->P;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            const double v = in[(size_t)b * P + p];
+            double r;
+            if (ctx->has_bounds[p]) {
+                double lo = ctx->lower[p], hi = ctx->upper[p];
+                if (lo > hi) std::swap(lo, hi);
+                r = mode == SEPAIHRD_CONSTRAINT_CLAMP ? std::min(std::max(v, lo), hi) : reflect_bound_host(v, lo, hi);
+            } else {
+                r = mode == SEPAIHRD_CONSTRAINT_CLAMP ? std::max(0.0, v) : std::abs(v);
+            }
+            out[(size_t)b * P + p] = r;
+        }
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_get_kernel_info(sepaihrd_ctx* ctx, sepaihrd_kernel_info* info) {
+    if (!ctx || !info) return SEPAIHRD_E_INVALID_ARG;
+    std::memset(info, 0, sizeof(*info));
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    LaunchInfo li{};
+    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? kernel_info_fma(ctx->dp, ctx->solver, &li)
+                                                     : kernel_info_strict(ctx->dp, ctx->solver, &li);
+    if (rc != 0) { ctx->last_error = "kernel_info failed"; return SEPAIHRD_E_HIP; }
+    info->lanes_per_chain = ctx->dp.lpc;
+    info->chains_per_wave = WAVE / ctx->dp.lpc;
+    info->block_threads = WAVE;
+    info->vgprs = li.vgprs; info->sgprs = li.sgprs; info->scratch_bytes = li.scratch;
+    info->lds_bytes = li.lds_static + (int)eval_lds_bytes(ctx->dp);
+    info->max_blocks_per_cu = li.max_blocks_per_cu;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device), ctx, return SEPAIHRD_E_HIP);
+    info->num_cus = prop.multiProcessorCount;
+    std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s lpc=%d solver=%d", li.name, ctx->dp.lpc,
+                  ctx->solver);
+    std::snprintf(info->device_name, sizeof(info->device_name), "%s (%s)", prop.name, prop.gcnArchName);
+    return SEPAIHRD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// csrc/sepaihrd_device.h -- structures shared by the C-ABI host code (sepaihrd_capi.cpp)
+// and the HIP kernels (sepaihrd_kernels.hip).  Internal: not part of the C ABI.
+#pragma once
+#include <stdint.h>
+
+namespace sepaihrd {
+
+constexpr int NUM_COMP = 11;          // S,E,P,A,I,H,ICU,R,D,CumH,CumICU
+constexpr int NUM_POP_COMP = 9;       // S..D
+constexpr int WAVE = 64;              // CDNA wavefront
+
+// scalar slots of a chain's parameter record (order fixed, see build_slot_tables)
+enum ScalarSlot {
+    SS_BETA = 0, SS_THETA, SS_SIGMA, SS_GAMMA_P, SS_GAMMA_A, SS_GAMMA_I, SS_GAMMA_H, SS_GAMMA_ICU,
+    SS_E0_MULT, SS_P0_MULT, SS_A0_MULT, SS_I0_MULT, SS_H0_MULT, SS_ICU0_MULT, SS_R0_MULT, SS_D0_MULT,
+    SS_RUNUP_DAYS, SS_SEED_EXPOSED,
+    SS_SCHEDULE0  // beta_values[0..nb) then kappa_values[0..nk)
+};
+// per-age vector fields
+enum VecField { VF_A = 0, VF_H_INFEC, VF_P, VF_H, VF_ICU, VF_D_H, VF_D_ICU, VF_D_COMM, VF_COUNT };
+
+// Problem data resident in HBM (uploaded once per ctx).  Every per-age table is padded
+// to `lpc` (lanes per chain = n rounded up to a power of two) so that lane `age` can
+// index it directly; padded ages have N = 0, zero state, zero rates and NaN observations.
+struct DevProblem {
+    int32_t n, lpc, T, n_obs, runup_offset, nb, nk, P, ns;
+    int32_t constraint_mode, kappa_calibrated, max_attempts, obs_rows_match;
+    double abs_tol, rel_tol, dt_hint, max_gap;
+    const double* times;         // [T]
+    const double* obs;           // [3][n_obs][lpc]  (H, ICU, D)
+    const double* lower;         // [P]
+    const double* upper;         // [P]
+    const int32_t* has_bounds;   // [P]
+    const int32_t* src_scalar;   // [ns] theta index feeding the slot, or -1
+    const double* base_scalar;   // [ns]
+    const int32_t* src_vec;      // [VF_COUNT][lpc]
+    const double* base_vec;      // [VF_COUNT][lpc]
+    const double* N;             // [lpc]
+    const double* age_fraction;  // [lpc]  N_i / sum(N)
+    const double* Mrow;          // [lpc][lpc]  Mrow[i*lpc+j] = M(i,j)
+    const double* init_state;    // [11][lpc]
+    const double* beta_ends;     // [nb]
+    const double* kappa_ends;    // [nk]
+};
+
+struct EvalOutputs {
+    double* loglik;     // [B]
+    int32_t* status;    // [B] or null
+    int32_t* n_accept;  // [B] or null
+    int32_t* n_reject;  // [B] or null
+    double* ll_parts;   // [B][3] or null
+    double* traj;       // [B][T][11][n] or null
+};
+
+struct LaunchInfo {
+    int vgprs, sgprs, lds_static, scratch, max_blocks_per_cu;
+    const char* name;
+};
+
+// implemented twice, once per arithmetic mode (separate translation units of the same source)
+int launch_eval_strict(const DevProblem& pb, int solver, const double* d_theta, int B,
+                       const EvalOutputs& out, void* stream);
+int launch_eval_fma(const DevProblem& pb, int solver, const double* d_theta, int B,
+                    const EvalOutputs& out, void* stream);
+int kernel_info_strict(const DevProblem& pb, int solver, LaunchInfo* info);
+int kernel_info_fma(const DevProblem& pb, int solver, LaunchInfo* info);
+
+inline int lanes_per_chain(int n) {
+    int l = 1;
+    while (l < n) l <<= 1;
+    return l;
+}
+inline size_t eval_lds_bytes(const DevProblem& pb) {
+    const int cpw = WAVE / pb.lpc;
+    return (size_t)cpw * (pb.P + pb.nb + pb.nk) * sizeof(double);
+}
+
+}  // namespace sepaihrd

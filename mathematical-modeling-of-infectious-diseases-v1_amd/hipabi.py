@@ -1,0 +1,225 @@
+"""ctypes view of the C ABI in include/sepaihrd_hip.h (test / bench plumbing).
+
+The reference-side binding a C++ maintainer would add is the adapter in ``host/``
+(see INTEGRATION.md); this module is what tests/ and bench.py use to drive the same
+entry points from Python.  No compute happens here and there is no fallback: if
+``libsepaihrd_hip.so`` is missing or no HIP device is present the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .problem import SEPAIHRDProblem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsepaihrd_hip.so")
+ABI_VERSION = 1
+LOWEST = -np.finfo(np.float64).max
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint8)
+
+
+class sepaihrd_problem(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_age", C.c_int32), ("n_times", C.c_int32), ("n_obs", C.c_int32),
+        ("n_beta", C.c_int32), ("n_kappa", C.c_int32), ("n_params", C.c_int32), ("solver", C.c_int32),
+        ("constraint_mode", C.c_int32), ("arith", C.c_int32), ("max_attempts", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("times", _dp), ("N", _dp), ("M", _dp),
+        ("a", _dp), ("h_infec", _dp), ("p", _dp), ("h", _dp), ("icu", _dp), ("d_H", _dp), ("d_ICU", _dp),
+        ("d_community", _dp),
+        ("beta_end_times", _dp), ("beta_values", _dp), ("kappa_end_times", _dp), ("kappa_values", _dp),
+        ("initial_state", _dp), ("obs_H", _dp), ("obs_ICU", _dp), ("obs_D", _dp),
+        ("param_field", _ip), ("param_index", _ip), ("lower", _dp), ("upper", _dp), ("has_bounds", _up),
+        ("beta", C.c_double), ("theta", C.c_double), ("sigma", C.c_double), ("gamma_p", C.c_double),
+        ("gamma_A", C.c_double), ("gamma_I", C.c_double), ("gamma_H", C.c_double), ("gamma_ICU", C.c_double),
+        ("multipliers", C.c_double * 8), ("runup_days", C.c_double), ("seed_exposed", C.c_double),
+        ("abs_err", C.c_double), ("rel_err", C.c_double), ("dt_hint", C.c_double),
+    ]
+
+
+class sepaihrd_kernel_info(C.Structure):
+    _fields_ = [
+        ("lanes_per_chain", C.c_int32), ("chains_per_wave", C.c_int32), ("block_threads", C.c_int32),
+        ("vgprs", C.c_int32), ("sgprs", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32),
+        ("max_blocks_per_cu", C.c_int32), ("num_cus", C.c_int32),
+        ("kernel_name", C.c_char * 128), ("device_name", C.c_char * 128),
+    ]
+
+
+# every symbol include/sepaihrd_hip.h declares
+EXPORTED_SYMBOLS = (
+    "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
+    "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
+    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info",
+)
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+            "the HIP path has no CPU fallback")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.sepaihrd_create.restype = vp
+    lib.sepaihrd_create.argtypes = [C.POINTER(sepaihrd_problem), C.c_int, C.c_char_p, C.c_int]
+    lib.sepaihrd_destroy.restype = None
+    lib.sepaihrd_destroy.argtypes = [vp]
+    lib.sepaihrd_last_error.restype = C.c_char_p
+    lib.sepaihrd_last_error.argtypes = [vp]
+    lib.sepaihrd_abi_version.restype = C.c_int
+    lib.sepaihrd_set_constraint_mode.argtypes = [vp, C.c_int]
+    lib.sepaihrd_set_arith.argtypes = [vp, C.c_int]
+    lib.sepaihrd_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.sepaihrd_eval_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    lib.sepaihrd_get_kernel_info.argtypes = [vp, C.POINTER(sepaihrd_kernel_info)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+def build_problem_struct(pb: SEPAIHRDProblem, keep: list) -> sepaihrd_problem:
+    """Fill the C struct; ``keep`` receives the arrays that must outlive the call."""
+    n = pb.n
+    s = sepaihrd_problem()
+    s.abi_version = ABI_VERSION
+    s.n_age, s.n_times, s.n_obs = n, pb.n_times, pb.n_obs
+    s.n_beta, s.n_kappa, s.n_params = len(pb.beta_values), len(pb.kappa_values), pb.n_params
+    s.solver, s.constraint_mode, s.arith = pb.solver, pb.constraint_mode, pb.arith
+    s.max_attempts = 0
+
+    def dbl(x):
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        if a.size == 0:
+            a = np.zeros(1)
+        keep.append(a)
+        return _ptr(a, _dp)
+
+    s.times, s.N = dbl(pb.times), dbl(pb.N)
+    s.M = dbl(np.asfortranarray(pb.M).ravel(order="F"))  # column-major like Eigen
+    for name in ("a", "h_infec", "p", "h", "icu", "d_H", "d_ICU", "d_community", "beta_end_times",
+                 "beta_values", "kappa_end_times", "kappa_values", "initial_state"):
+        setattr(s, name, dbl(getattr(pb, name)))
+    s.obs_H, s.obs_ICU, s.obs_D = dbl(pb.obs_H), dbl(pb.obs_ICU), dbl(pb.obs_D)
+    codes, idxs = pb.field_map()
+    lo, hi, has = pb.bounds_arrays()
+    keep.extend([codes, idxs, has])
+    s.param_field, s.param_index = _ptr(codes, _ip), _ptr(idxs, _ip)
+    s.lower, s.upper, s.has_bounds = dbl(lo), dbl(hi), _ptr(has, _up)
+    s.beta, s.theta, s.sigma, s.gamma_p = pb.beta, pb.theta, pb.sigma, pb.gamma_p
+    s.gamma_A, s.gamma_I, s.gamma_H, s.gamma_ICU = pb.gamma_A, pb.gamma_I, pb.gamma_H, pb.gamma_ICU
+    for i in range(8):
+        s.multipliers[i] = float(pb.multipliers[i])
+    s.runup_days, s.seed_exposed = pb.runup_days, pb.seed_exposed
+    s.abs_err, s.rel_err, s.dt_hint = pb.abs_err, pb.rel_err, pb.dt_hint
+    return s
+
+
+class HipObjective:
+    """Batched SEPAIHRD objective on one MI355X; mirrors IObjectiveFunction for B thetas."""
+
+    def __init__(self, pb: SEPAIHRDProblem, device: int = -1):
+        self.lib = load_library()
+        self.pb = pb
+        keep: list = []
+        st = build_problem_struct(pb, keep)
+        err = C.create_string_buffer(512)
+        self.ctx = self.lib.sepaihrd_create(C.byref(st), device, err, len(err))
+        if not self.ctx:
+            raise RuntimeError("sepaihrd_create failed: " + err.value.decode())
+        self.P, self.n, self.T = pb.n_params, pb.n, pb.n_times
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sepaihrd_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): " + self.lib.sepaihrd_last_error(self.ctx).decode())
+
+    def getParameterNames(self):
+        return list(self.pb.param_names)
+
+    def set_constraint_mode(self, mode: int):
+        self._check(self.lib.sepaihrd_set_constraint_mode(self.ctx, mode), "set_constraint_mode")
+
+    def set_arith(self, arith: int):
+        self._check(self.lib.sepaihrd_set_arith(self.ctx, arith), "set_arith")
+
+    def calculate(self, theta) -> float:
+        return float(self.eval_batch(np.asarray(theta, dtype=np.float64)[None, :])["loglik"][0])
+
+    def eval_batch(self, theta, want_traj: bool = False) -> dict:
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.ndim != 2 or th.shape[1] != self.P:
+            raise ValueError(f"theta must be B x {self.P}")
+        B = th.shape[0]
+        out = {
+            "loglik": np.empty(B), "status": np.empty(B, dtype=np.int32),
+            "n_accept": np.empty(B, dtype=np.int32), "n_reject": np.empty(B, dtype=np.int32),
+            "ll_parts": np.empty((B, 3)),
+        }
+        traj = np.empty((B, self.T, 11 * self.n)) if want_traj else None
+        rc = self.lib.sepaihrd_eval_batch(
+            self.ctx, th.ctypes.data, B, out["loglik"].ctypes.data, out["status"].ctypes.data,
+            out["n_accept"].ctypes.data, out["n_reject"].ctypes.data, out["ll_parts"].ctypes.data,
+            traj.ctypes.data if want_traj else None)
+        self._check(rc, "sepaihrd_eval_batch")
+        if want_traj:
+            out["traj"] = traj
+        return out
+
+    def eval_batch_device(self, d_theta, d_loglik, d_status=None, d_n_accept=None, d_n_reject=None,
+                          d_ll_parts=None, d_traj=None, stream: int = 0, B: Optional[int] = None):
+        """Arguments are torch CUDA tensors (or raw device addresses); async on ``stream``."""
+        def addr(t):
+            if t is None:
+                return None
+            return t if isinstance(t, int) else t.data_ptr()
+        if B is None:
+            B = int(d_theta.shape[0])
+        rc = self.lib.sepaihrd_eval_batch_device(self.ctx, addr(d_theta), B, addr(d_loglik), addr(d_status),
+                                                 addr(d_n_accept), addr(d_n_reject), addr(d_ll_parts),
+                                                 addr(d_traj), stream if stream else None)
+        self._check(rc, "sepaihrd_eval_batch_device")
+
+    def apply_constraints(self, theta, mode: int) -> np.ndarray:
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        out = np.empty_like(th)
+        self._check(self.lib.sepaihrd_apply_constraints(self.ctx, mode, th.ctypes.data, th.shape[0],
+                                                        out.ctypes.data), "apply_constraints")
+        return out
+
+    def kernel_info(self) -> dict:
+        info = sepaihrd_kernel_info()
+        self._check(self.lib.sepaihrd_get_kernel_info(self.ctx, C.byref(info)), "get_kernel_info")
+        d = {k: getattr(info, k) for k, _ in info._fields_}
+        d["kernel_name"] = info.kernel_name.decode()
+        d["device_name"] = info.device_name.decode()
+        return d

@@ -1,0 +1,21 @@
+"""Import helper: the package directory name required by the build contract
+(``mathematical-modeling-of-infectious-diseases-v1_amd``) is not a valid Python identifier,
+so it is loaded under the module name ``mmid_amd``."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, "mathematical-modeling-of-infectious-diseases-v1_amd")
+MODULE_NAME = "mmid_amd"
+
+
+def load():
+    if MODULE_NAME in sys.modules:
+        return sys.modules[MODULE_NAME]
+    spec = importlib.util.spec_from_file_location(
+        MODULE_NAME, os.path.join(PKG_DIR, "__init__.py"), submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[MODULE_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,221 @@
+// oracle/oracle_capi.cpp -- TEST INFRASTRUCTURE (see sepaihrd_oracle.hpp header).
+#include "oracle_capi.h"
+#include "sepaihrd_oracle.hpp"
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+namespace {
+std::vector<std::string> split_lines(const char* s) {
+    std::vector<std::string> out;
+    if (!s) return out;
+    std::stringstream ss(s);
+    std::string line;
+    while (std::getline(ss, line, '\n'))
+        if (!line.empty()) out.push_back(line);
+    return out;
+}
+std::vector<double> vec(const double* p, int n) {
+    return p ? std::vector<double>(p, p + n) : std::vector<double>();
+}
+struct Handle {
+    oracle::Problem pb;
+};
+}  // namespace
+
+extern "C" {
+
+void* oracle_create(const oracle_problem* q, char* err, int errlen) {
+    try {
+        auto* h = new Handle();
+        oracle::Problem& pb = h->pb;
+        oracle::Params& P = pb.base;
+        const int n = q->n;
+        P.n = n;
+        P.N = vec(q->N, n);
+        P.M = vec(q->M, n * n);
+        P.a = vec(q->a, n); P.h_infec = vec(q->h_infec, n); P.p = vec(q->p, n); P.h = vec(q->h, n);
+        P.icu = vec(q->icu, n); P.d_H = vec(q->d_H, n); P.d_ICU = vec(q->d_ICU, n);
+        P.d_community = vec(q->d_community, n);
+        P.beta = q->beta; P.theta = q->theta; P.sigma = q->sigma; P.gamma_p = q->gamma_p;
+        P.gamma_A = q->gamma_A; P.gamma_I = q->gamma_I; P.gamma_H = q->gamma_H; P.gamma_ICU = q->gamma_ICU;
+        P.beta_end_times = vec(q->beta_end_times, q->n_beta);
+        P.beta_values = vec(q->beta_values, q->n_beta);
+        P.kappa_end_times = vec(q->kappa_end_times, q->n_kappa);
+        P.kappa_values = vec(q->kappa_values, q->n_kappa);
+        P.E0_multiplier = q->multipliers[0]; P.P0_multiplier = q->multipliers[1];
+        P.A0_multiplier = q->multipliers[2]; P.I0_multiplier = q->multipliers[3];
+        P.H0_multiplier = q->multipliers[4]; P.ICU0_multiplier = q->multipliers[5];
+        P.R0_multiplier = q->multipliers[6]; P.D0_multiplier = q->multipliers[7];
+        P.runup_days = q->runup_days; P.seed_exposed = q->seed_exposed;
+        oracle::Model check(P);  // validates sizes
+        pb.time_points = vec(q->times, q->n_times);
+        pb.initial_state = vec(q->initial_state, oracle::NUM_COMPARTMENTS * n);
+        pb.num_obs_rows = q->n_obs;
+        pb.obs_H = vec(q->obs_H, q->n_obs * n);
+        pb.obs_ICU = vec(q->obs_ICU, q->n_obs * n);
+        pb.obs_D = vec(q->obs_D, q->n_obs * n);
+        pb.solver = q->solver == 1 ? oracle::CASH_KARP54 : oracle::DOPRI5;
+        pb.abs_err = q->abs_err; pb.rel_err = q->rel_err; pb.dt_hint = q->dt_hint;
+        pb.pm.names = split_lines(q->param_names);
+        pb.pm.npi_names = split_lines(q->npi_names);
+        if ((int)pb.pm.names.size() != q->n_params) throw std::invalid_argument("param_names count");
+        if ((int)pb.pm.npi_names.size() != q->n_kappa - 1) throw std::invalid_argument("npi_names count");
+        for (int i = 0; i < q->n_params; ++i) {
+            pb.pm.sigmas[pb.pm.names[i]] = q->sigmas ? q->sigmas[i] : 0.0;
+            if (q->lower && q->upper && !std::isnan(q->lower[i]))
+                pb.pm.bounds[pb.pm.names[i]] = {q->lower[i], q->upper[i]};
+        }
+        pb.pm.mode = q->constraint_mode == 1 ? oracle::MCMC_REFLECT : oracle::OPTIMIZATION_CLAMP;
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) std::snprintf(err, errlen, "%s", e.what());
+        return nullptr;
+    }
+}
+
+void oracle_destroy(void* h) { delete static_cast<Handle*>(h); }
+
+void oracle_set_constraint_mode(void* h, int mode) {
+    static_cast<Handle*>(h)->pb.pm.mode = mode == 1 ? oracle::MCMC_REFLECT : oracle::OPTIMIZATION_CLAMP;
+}
+
+int oracle_eval_batch(void* hv, const double* theta, int B, double* loglik, int32_t* status,
+                      int32_t* n_accept, int32_t* n_reject, double* ll_parts, double* traj,
+                      int nthreads) {
+    const Handle* h = static_cast<Handle*>(hv);
+    const int P = (int)h->pb.pm.names.size();
+    const size_t traj_len = h->pb.time_points.size() * oracle::NUM_COMPARTMENTS * h->pb.base.n;
+    (void)nthreads;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+        std::vector<double> th(theta + (size_t)b * P, theta + (size_t)(b + 1) * P);
+        oracle::EvalInfo info;
+        std::vector<double> tr;
+        double v = oracle::objective(h->pb, th, &info, traj ? &tr : nullptr);
+        loglik[b] = v;
+        if (status) status[b] = info.status;
+        if (n_accept) n_accept[b] = (int32_t)info.steps.accepted;
+        if (n_reject) n_reject[b] = (int32_t)info.steps.rejected;
+        if (ll_parts) {
+            ll_parts[3 * b + 0] = info.ll_hosp;
+            ll_parts[3 * b + 1] = info.ll_icu;
+            ll_parts[3 * b + 2] = info.ll_deaths;
+        }
+        if (traj) {
+            if (tr.size() == traj_len) std::memcpy(traj + (size_t)b * traj_len, tr.data(), traj_len * 8);
+            else std::fill(traj + (size_t)b * traj_len, traj + (size_t)(b + 1) * traj_len, 0.0);
+        }
+    }
+    return 0;
+}
+
+static int updated_model(const Handle* h, const double* theta, oracle::Model& m) {
+    if (!theta) return 0;
+    const int P = (int)h->pb.pm.names.size();
+    try {
+        h->pb.pm.updateModelParameters(std::vector<double>(theta, theta + P), m);
+    } catch (...) { return 1; }
+    return 0;
+}
+
+int oracle_rhs(void* hv, const double* theta, const double* x, double t, double* dxdt) {
+    const Handle* h = static_cast<Handle*>(hv);
+    oracle::Model m(h->pb.base);
+    if (updated_model(h, theta, m)) return 1;
+    m.rhs(x, dxdt, t);
+    return 0;
+}
+
+double oracle_beta_kappa(void* hv, const double* theta, double t, double* beta, double* kappa) {
+    const Handle* h = static_cast<Handle*>(hv);
+    oracle::Model m(h->pb.base);
+    updated_model(h, theta, m);
+    const double b = m.beta(t), k = m.kappa(t);
+    if (beta) *beta = b;
+    if (kappa) *kappa = k;
+    return b * k;
+}
+
+double oracle_poisson_loglik(const double* sim, const double* obs, int rows, int cols) {
+    return oracle::poisson_loglik(sim, obs, rows, cols);
+}
+
+int oracle_apply_constraints(void* hv, int mode, const double* in, double* out) {
+    const Handle* h = static_cast<Handle*>(hv);
+    oracle::ParameterManager pm = h->pb.pm;
+    pm.mode = mode == 1 ? oracle::MCMC_REFLECT : oracle::OPTIMIZATION_CLAMP;
+    const int P = (int)pm.names.size();
+    std::vector<double> c = pm.applyConstraints(std::vector<double>(in, in + P));
+    std::copy(c.begin(), c.end(), out);
+    return 0;
+}
+
+int oracle_jitter_draws(void* hv, int mode, const double* base, uint32_t seed0, int B, double* out) {
+    const Handle* h = static_cast<Handle*>(hv);
+    oracle::ParameterManager pm = h->pb.pm;
+    pm.mode = mode == 1 ? oracle::MCMC_REFLECT : oracle::OPTIMIZATION_CLAMP;
+    const int P = (int)pm.names.size();
+    std::vector<double> b0(base, base + P);
+    for (int b = 0; b < B; ++b) {
+        std::vector<double> c = oracle::jitter_draw(pm, b0, seed0 + (uint32_t)b);
+        std::copy(c.begin(), c.end(), out + (size_t)b * P);
+    }
+    return 0;
+}
+
+uint64_t oracle_cache_hash(const double* p, int size) { return oracle::cache_hash(p, size); }
+
+void oracle_std_normals(uint32_t seed, int count, double* out) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    for (int i = 0; i < count; ++i) out[i] = normal(rng);
+}
+
+int oracle_mh(void* hv, int iterations, int burn_in, int adaptation_period, int thinning,
+              double reg_eps, double target_acc, int adapt_scale, const double* x0, uint32_t seed,
+              double* best, double* best_value, int32_t* accepted, double* final_scale,
+              unsigned char* accept_trace, double* samples, double* sample_values,
+              int32_t* n_samples, double* final_cov) {
+    const Handle* h = static_cast<Handle*>(hv);
+    oracle::Problem pb = h->pb;  // private copy: the sampler flips the constraint mode
+    const int P = (int)pb.pm.names.size();
+    oracle::MHSettings cfg;
+    cfg.iterations = iterations; cfg.burn_in = burn_in; cfg.adaptation_period = adaptation_period;
+    cfg.thinning = std::max(1, thinning); cfg.regularization_epsilon = reg_eps;
+    cfg.target_acceptance_rate = target_acc; cfg.adapt_scale = adapt_scale != 0;
+    oracle::Objective f = [&pb](const std::vector<double>& th) {
+        oracle::EvalInfo info;
+        double v = oracle::objective(pb, th, &info, nullptr);
+        if (info.status == 2) throw std::runtime_error("SimulationException");
+        return v;
+    };
+    oracle::MHResult r = oracle::metropolis_hastings(cfg, std::vector<double>(x0, x0 + P), f, pb.pm, seed);
+    if (best) std::copy(r.best.begin(), r.best.end(), best);
+    if (best_value) *best_value = r.best_value;
+    if (accepted) *accepted = r.accepted;
+    if (final_scale) *final_scale = r.final_scale;
+    if (accept_trace) std::copy(r.accept_trace.begin(), r.accept_trace.end(), accept_trace);
+    if (n_samples) *n_samples = (int32_t)r.samples.size();
+    if (samples)
+        for (size_t i = 0; i < r.samples.size(); ++i)
+            std::copy(r.samples[i].begin(), r.samples[i].end(), samples + i * P);
+    if (sample_values) std::copy(r.sample_values.begin(), r.sample_values.end(), sample_values);
+    if (final_cov) std::copy(r.final_cov.begin(), r.final_cov.end(), final_cov);
+    return 0;
+}
+
+int oracle_num_threads(void) {
+#if defined(_OPENMP)
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

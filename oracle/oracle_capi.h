@@ -1,0 +1,57 @@
+/* oracle/oracle_capi.h -- TEST INFRASTRUCTURE.  Flat C view of the CPU oracle
+ * (oracle/sepaihrd_oracle.hpp) for ctypes.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so. */
+#ifndef SEPAIHRD_ORACLE_CAPI_H
+#define SEPAIHRD_ORACLE_CAPI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_problem {
+    int32_t n, n_times, n_obs, n_beta, n_kappa, n_params, solver, constraint_mode;
+    const double *times, *N, *M; /* M column-major n x n */
+    const double *a, *h_infec, *p, *h, *icu, *d_H, *d_ICU, *d_community;
+    const double *beta_end_times, *beta_values;   /* n_beta (may be 0) */
+    const double *kappa_end_times, *kappa_values; /* n_kappa >= 1, baseline first */
+    const double *initial_state;                  /* 11 n */
+    const double *obs_H, *obs_ICU, *obs_D;        /* n_obs x n row-major */
+    const double *lower, *upper, *sigmas;         /* n_params; lower = NaN -> no bounds entry */
+    const char *param_names;                      /* '\n'-joined, n_params names */
+    const char *npi_names;                        /* '\n'-joined, n_kappa-1 names */
+    double beta, theta, sigma, gamma_p, gamma_A, gamma_I, gamma_H, gamma_ICU;
+    double multipliers[8]; /* E0,P0,A0,I0,H0,ICU0,R0,D0 */
+    double runup_days, seed_exposed;
+    double abs_err, rel_err, dt_hint;
+} oracle_problem;
+
+void *oracle_create(const oracle_problem *pb, char *err, int errlen);
+void oracle_destroy(void *h);
+void oracle_set_constraint_mode(void *h, int mode);
+
+/* theta: B x P chain-major.  traj (nullable): B x T x 11n.  ll_parts (nullable): B x 3. */
+int oracle_eval_batch(void *h, const double *theta, int B, double *loglik, int32_t *status,
+                      int32_t *n_accept, int32_t *n_reject, double *ll_parts, double *traj,
+                      int nthreads);
+/* RHS with the model updated by theta (theta may be NULL -> base parameters). */
+int oracle_rhs(void *h, const double *theta, const double *x, double t, double *dxdt);
+double oracle_beta_kappa(void *h, const double *theta, double t, double *beta, double *kappa);
+double oracle_poisson_loglik(const double *sim, const double *obs, int rows, int cols);
+int oracle_apply_constraints(void *h, int mode, const double *in, double *out);
+/* chain b: mt19937(seed0 + b), theta_b = constrain(base + sigma * N(0,1)), reflect or clamp per mode */
+int oracle_jitter_draws(void *h, int mode, const double *base, uint32_t seed0, int B, double *out);
+uint64_t oracle_cache_hash(const double *p, int size);
+/* n standard normals from mt19937(seed) with ONE persistent std::normal_distribution */
+void oracle_std_normals(uint32_t seed, int count, double *out);
+/* Adaptive Metropolis, one chain. samples: (iterations/thinning + 1) x P capacity given by caller. */
+int oracle_mh(void *h, int iterations, int burn_in, int adaptation_period, int thinning,
+              double reg_eps, double target_acc, int adapt_scale, const double *x0, uint32_t seed,
+              double *best, double *best_value, int32_t *accepted, double *final_scale,
+              unsigned char *accept_trace, double *samples, double *sample_values,
+              int32_t *n_samples, double *final_cov);
+int oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_dp = C.POINTER(C.c_double)
+
+
+class oracle_problem(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("n_times", C.c_int32), ("n_obs", C.c_int32), ("n_beta", C.c_int32),
+        ("n_kappa", C.c_int32), ("n_params", C.c_int32), ("solver", C.c_int32), ("constraint_mode", C.c_int32),
+        ("times", _dp), ("N", _dp), ("M", _dp),
+        ("a", _dp), ("h_infec", _dp), ("p", _dp), ("h", _dp), ("icu", _dp), ("d_H", _dp), ("d_ICU", _dp),
+        ("d_community", _dp),
+        ("beta_end_times", _dp), ("beta_values", _dp), ("kappa_end_times", _dp), ("kappa_values", _dp),
+        ("initial_state", _dp), ("obs_H", _dp), ("obs_ICU", _dp), ("obs_D", _dp),
+        ("lower", _dp), ("upper", _dp), ("sigmas", _dp),
+        ("param_names", C.c_char_p), ("npi_names", C.c_char_p),
+        ("beta", C.c_double), ("theta", C.c_double), ("sigma", C.c_double), ("gamma_p", C.c_double),
+        ("gamma_A", C.c_double), ("gamma_I", C.c_double), ("gamma_H", C.c_double), ("gamma_ICU", C.c_double),
+        ("multipliers", C.c_double * 8), ("runup_days", C.c_double), ("seed_exposed", C.c_double),
+        ("abs_err", C.c_double), ("rel_err", C.c_double), ("dt_hint", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def build(native: bool = False) -> None:
+    import subprocess
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+
+
+def load(path: str | None = None) -> C.CDLL:
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        build(native=p.endswith("_native.so"))
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.oracle_create.restype = vp
+    lib.oracle_create.argtypes = [C.POINTER(oracle_problem), C.c_char_p, C.c_int]
+    lib.oracle_destroy.argtypes = [vp]
+    lib.oracle_set_constraint_mode.argtypes = [vp, C.c_int]
+    lib.oracle_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.oracle_rhs.argtypes = [vp, vp, vp, C.c_double, vp]
+    lib.oracle_beta_kappa.restype = C.c_double
+    lib.oracle_beta_kappa.argtypes = [vp, vp, C.c_double, vp, vp]
+    lib.oracle_poisson_loglik.restype = C.c_double
+    lib.oracle_poisson_loglik.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.oracle_apply_constraints.argtypes = [vp, C.c_int, vp, vp]
+    lib.oracle_jitter_draws.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, vp]
+    lib.oracle_cache_hash.restype = C.c_uint64
+    lib.oracle_cache_hash.argtypes = [vp, C.c_int]
+    lib.oracle_std_normals.argtypes = [C.c_uint32, C.c_int, vp]
+    lib.oracle_mh.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
+                              C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.oracle_num_threads.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Oracle:
+    """CPU restatement of SEPAIHRDObjectiveFunction for a SEPAIHRDProblem (the checker)."""
+
+    def __init__(self, pb, lib_path: str | None = None):
+        self.lib = load(lib_path)
+        self.pb = pb
+        self._keep = []
+        s = oracle_problem()
+        s.n, s.n_times, s.n_obs = pb.n, pb.n_times, pb.n_obs
+        s.n_beta, s.n_kappa, s.n_params = len(pb.beta_values), len(pb.kappa_values), pb.n_params
+        s.solver, s.constraint_mode = pb.solver, pb.constraint_mode
+
+        def dbl(x):
+            a = np.ascontiguousarray(x, dtype=np.float64)
+            if a.size == 0:
+                a = np.zeros(1)
+            self._keep.append(a)
+            return a.ctypes.data_as(_dp)
+
+        s.times, s.N = dbl(pb.times), dbl(pb.N)
+        s.M = dbl(np.asarray(pb.M).ravel(order="F"))
+        for name in ("a", "h_infec", "p", "h", "icu", "d_H", "d_ICU", "d_community", "beta_end_times",
+                     "beta_values", "kappa_end_times", "kappa_values", "initial_state"):
+            setattr(s, name, dbl(getattr(pb, name)))
+        s.obs_H, s.obs_ICU, s.obs_D = dbl(pb.obs_H), dbl(pb.obs_ICU), dbl(pb.obs_D)
+        lo, hi, has = pb.bounds_arrays()
+        lo = np.where(has.astype(bool), lo, np.nan)
+        s.lower, s.upper, s.sigmas = dbl(lo), dbl(hi), dbl(pb.sigma_array())
+        s.param_names = "\n".join(pb.param_names).encode()
+        s.npi_names = "\n".join(pb.npi_names).encode()
+        s.beta, s.theta, s.sigma, s.gamma_p = pb.beta, pb.theta, pb.sigma, pb.gamma_p
+        s.gamma_A, s.gamma_I, s.gamma_H, s.gamma_ICU = pb.gamma_A, pb.gamma_I, pb.gamma_H, pb.gamma_ICU
+        for i in range(8):
+            s.multipliers[i] = float(pb.multipliers[i])
+        s.runup_days, s.seed_exposed = pb.runup_days, pb.seed_exposed
+        s.abs_err, s.rel_err, s.dt_hint = pb.abs_err, pb.rel_err, pb.dt_hint
+        err = C.create_string_buffer(512)
+        self.h = self.lib.oracle_create(C.byref(s), err, len(err))
+        if not self.h:
+            raise RuntimeError("oracle_create failed: " + err.value.decode())
+        self.P, self.n, self.T = pb.n_params, pb.n, pb.n_times
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.oracle_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_constraint_mode(self, mode: int):
+        self.lib.oracle_set_constraint_mode(self.h, mode)
+
+    def eval_batch(self, theta, want_traj: bool = False, nthreads: int = 0) -> dict:
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        assert th.shape[1] == self.P
+        B = th.shape[0]
+        out = {"loglik": np.empty(B), "status": np.empty(B, dtype=np.int32),
+               "n_accept": np.empty(B, dtype=np.int32), "n_reject": np.empty(B, dtype=np.int32),
+               "ll_parts": np.empty((B, 3))}
+        traj = np.empty((B, self.T, 11 * self.n)) if want_traj else None
+        if nthreads <= 0:
+            nthreads = self.lib.oracle_num_threads()
+        self.lib.oracle_eval_batch(self.h, th.ctypes.data, B, out["loglik"].ctypes.data,
+                                   out["status"].ctypes.data, out["n_accept"].ctypes.data,
+                                   out["n_reject"].ctypes.data, out["ll_parts"].ctypes.data,
+                                   traj.ctypes.data if want_traj else None, nthreads)
+        if want_traj:
+            out["traj"] = traj
+        return out
+
+    def calculate(self, theta) -> float:
+        return float(self.eval_batch(theta, nthreads=1)["loglik"][0])
+
+    def rhs(self, x, t, theta=None) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        dx = np.empty_like(x)
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        rc = self.lib.oracle_rhs(self.h, th.ctypes.data if th is not None else None, x.ctypes.data, float(t),
+                                 dx.ctypes.data)
+        if rc:
+            raise RuntimeError("updateModelParameters threw")
+        return dx
+
+    def beta_kappa(self, t, theta=None):
+        b, k = C.c_double(), C.c_double()
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        self.lib.oracle_beta_kappa(self.h, th.ctypes.data if th is not None else None, float(t), C.byref(b),
+                                   C.byref(k))
+        return b.value, k.value
+
+    def apply_constraints(self, theta, mode: int) -> np.ndarray:
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        out = np.empty_like(th)
+        for b in range(th.shape[0]):
+            self.lib.oracle_apply_constraints(self.h, mode, th[b].ctypes.data, out[b].ctypes.data)
+        return out
+
+    def jitter_draws(self, base, seed0: int, B: int, mode: int = 1) -> np.ndarray:
+        base = np.ascontiguousarray(base, dtype=np.float64)
+        out = np.empty((B, self.P))
+        self.lib.oracle_jitter_draws(self.h, mode, base.ctypes.data, seed0, B, out.ctypes.data)
+        return out
+
+    def metropolis_hastings(self, x0, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
+                            thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
+                            adapt_scale: bool = True) -> dict:
+        P = self.P
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        cap = iterations // max(1, thinning) + 2
+        best = np.empty(P)
+        best_value, final_scale = C.c_double(), C.c_double()
+        accepted, n_samples = C.c_int32(), C.c_int32()
+        trace = np.zeros(max(iterations - 1, 1), dtype=np.uint8)
+        samples = np.empty((cap, P))
+        values = np.empty(cap)
+        cov = np.empty((P, P))
+        self.lib.oracle_mh(self.h, iterations, burn_in, adaptation_period, thinning, reg_eps, target_acc,
+                           int(adapt_scale), x0.ctypes.data, seed, best.ctypes.data, C.byref(best_value),
+                           C.byref(accepted), C.byref(final_scale), trace.ctypes.data, samples.ctypes.data,
+                           values.ctypes.data, C.byref(n_samples), cov.ctypes.data)
+        ns = n_samples.value
+        return {"best": best, "best_value": best_value.value, "accepted": accepted.value,
+                "final_scale": final_scale.value, "accept_trace": trace[:iterations - 1],
+                "samples": samples[:ns], "sample_values": values[:ns], "final_cov": cov}
+
+
+def poisson_loglik(sim, obs) -> float:
+    lib = load()
+    sim = np.ascontiguousarray(sim, dtype=np.float64)
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    return lib.oracle_poisson_loglik(sim.ctypes.data, obs.ctypes.data, sim.shape[0], sim.shape[1])
+
+
+def cache_hash(p) -> int:
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    return load().oracle_cache_hash(p.ctypes.data, p.size)
+
+
+def std_normals(seed: int, count: int) -> np.ndarray:
+    out = np.empty(count)
+    load().oracle_std_normals(seed, count, out.ctypes.data)
+    return out

@@ -1,0 +1,960 @@
+// =============================================================================
+// oracle/sepaihrd_oracle.hpp  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement (plain C++17, no dependencies) of the reference's MCMC
+// likelihood hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may link or call this.  The product path (HIP kernels behind
+// include/sepaihrd_hip.h) never routes through it.
+//
+// PARITY STATUS: "parity unpinned" for the integrator.  The adaptive RK
+// arithmetic lives in Boost.Odeint (find_package(Boost) in the reference's
+// CMakeLists.txt:34, version unpinned, sources absent from /root/reference and
+// from this image) and the reference holds no test that pins a trajectory or a
+// full log-likelihood value.  The integrator below restates Boost.Odeint's
+// published algorithm (integrate_times + controlled_runge_kutta +
+// runge_kutta_dopri5 / runge_kutta_cash_karp54) and is anchored on the
+// reference's call sites.  What IS pinned by the reference's own tests:
+//   * the Poisson log-likelihood closed form
+//     (tests/model/SEPAIHRDObjectivefunctionTest.cpp:688-752, tol 1e-8);
+//   * structural properties of calculate() (same file :334-685).
+// Independent cross-checks (SciPy DOP853 / Radau at rtol 1e-12, mpmath RHS
+// values) are committed under tests/golden/ with their generating script.
+//
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference).
+// =============================================================================
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <limits>
+#include <map>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace oracle {
+
+using state_type = std::vector<double>;
+
+// include/model/ModelConstants.hpp:9,18,22
+constexpr double MIN_POPULATION_FOR_DIVISION = 1e-9;
+constexpr int NUM_COMPARTMENTS = 11;
+constexpr int NUM_POPULATION_COMPARTMENTS = 9;
+constexpr int MAX_AGE_CLASSES = 64;  // oracle-side bound (the reference is generic in n)
+
+// -----------------------------------------------------------------------------
+// Model parameters: include/model/parameters/SEPAIHRDParameters.hpp:20-124
+// M is stored column-major like Eigen::MatrixXd (M[j*n+i] == M(i,j)).
+// kappa_end_times / kappa_values include the baseline period at index 0, as
+// AgeSEPAIHRDModel::getModelParameters returns them
+// (src/model/AgeSEPAIHRDModel.cpp:316-321).
+// -----------------------------------------------------------------------------
+struct Params {
+    int n = 0;
+    std::vector<double> N, M;
+    double beta = 0, theta = 0, sigma = 0, gamma_p = 0, gamma_A = 0, gamma_I = 0,
+           gamma_H = 0, gamma_ICU = 0;
+    std::vector<double> a, h_infec, p, h, icu, d_H, d_ICU, d_community;
+    std::vector<double> beta_end_times, beta_values;
+    std::vector<double> kappa_end_times, kappa_values;
+    double E0_multiplier = 1, P0_multiplier = 1, A0_multiplier = 1, I0_multiplier = 1,
+           H0_multiplier = 1, ICU0_multiplier = 1, R0_multiplier = 1, D0_multiplier = 1;
+    double runup_days = 30.0, seed_exposed = 10.0;
+};
+
+// -----------------------------------------------------------------------------
+// Piecewise-constant schedules.
+// kappa(t): src/model/PieceWiseConstantNPIStrategy.cpp:86-127
+// beta(t) : src/model/PiecewiseConstantParameterStrategy.cpp:37-74, built in
+//           src/model/AgeSEPAIHRDModel.cpp:352-362 (first entry = baseline).
+// The reference keeps a mutable "last period" cache; both of its branches agree
+// with the pure lower_bound lookup written here.
+// -----------------------------------------------------------------------------
+inline double piecewise_value(const std::vector<double>& ends_after, const double* vals_after,
+                              double baseline_value, double baseline_end, double t) {
+    if (t <= baseline_end) return baseline_value;
+    if (ends_after.empty()) return baseline_value;
+    auto it = std::lower_bound(ends_after.begin(), ends_after.end(), t);
+    if (it == ends_after.end()) return vals_after[ends_after.size() - 1];
+    return vals_after[it - ends_after.begin()];
+}
+
+inline double kappa_at(const Params& P, double t) {
+    // PieceWiseConstantNPIStrategy.cpp:87-89: t < 0 -> baseline
+    if (t < 0) return P.kappa_values.front();
+    std::vector<double> ends(P.kappa_end_times.begin() + 1, P.kappa_end_times.end());
+    return piecewise_value(ends, P.kappa_values.data() + 1, P.kappa_values.front(),
+                           P.kappa_end_times.front(), t);
+}
+
+inline double beta_at(const Params& P, double t) {
+    // AgeSEPAIHRDModel.cpp:352-368: schedule only when sizes match and non-empty
+    if (P.beta_values.empty() || P.beta_end_times.empty() ||
+        P.beta_values.size() != P.beta_end_times.size())
+        return P.beta;
+    std::vector<double> ends(P.beta_end_times.begin() + 1, P.beta_end_times.end());
+    return piecewise_value(ends, P.beta_values.data() + 1, P.beta_values.front(),
+                           P.beta_end_times.front(), t);
+}
+
+// -----------------------------------------------------------------------------
+// Model with the pre-computed members the reference keeps.
+// -----------------------------------------------------------------------------
+struct Model {
+    Params P;
+    std::vector<double> inv_N;
+    // lookups hoisted out of the RHS (same values as kappa_at/beta_at)
+    std::vector<double> kappa_ends_after, beta_ends_after;
+    bool has_beta_schedule = false;
+
+    explicit Model(const Params& p) { set(p); }
+    // src/model/AgeSEPAIHRDModel.cpp:325-363 setModelParameters
+    void set(const Params& p) {
+        P = p;
+        if (P.n <= 0 || P.n > MAX_AGE_CLASSES) throw std::invalid_argument("Model: bad n");
+        if (P.kappa_values.empty() || P.kappa_values.size() != P.kappa_end_times.size())
+            throw std::invalid_argument("Model: kappa schedule needs >= 1 (baseline) entry");
+        if (P.d_community.empty()) P.d_community.assign(P.n, 0.0);
+        inv_N.resize(P.n);
+        for (int i = 0; i < P.n; ++i)
+            inv_N[i] = (P.N[i] > MIN_POPULATION_FOR_DIVISION) ? (1.0 / P.N[i]) : 0.0;
+        kappa_ends_after.assign(P.kappa_end_times.begin() + (P.kappa_end_times.empty() ? 0 : 1),
+                                P.kappa_end_times.end());
+        has_beta_schedule = !P.beta_values.empty() && !P.beta_end_times.empty() &&
+                            P.beta_values.size() == P.beta_end_times.size();
+        if (has_beta_schedule)
+            beta_ends_after.assign(P.beta_end_times.begin() + 1, P.beta_end_times.end());
+        else
+            beta_ends_after.clear();
+    }
+    double kappa(double t) const {
+        if (t < 0) return P.kappa_values.front();
+        return piecewise_value(kappa_ends_after, P.kappa_values.data() + 1,
+                               P.kappa_values.front(), P.kappa_end_times.front(), t);
+    }
+    double beta(double t) const {
+        if (!has_beta_schedule) return P.beta;
+        return piecewise_value(beta_ends_after, P.beta_values.data() + 1, P.beta_values.front(),
+                               P.beta_end_times.front(), t);
+    }
+
+    // src/model/AgeSEPAIHRDModel.cpp:101-228 computeDerivatives.
+    // Operation order is kept statement by statement (no FMA: the reference
+    // builds with -O3 on baseline x86-64, CMakeLists.txt:25-29).
+    void rhs(const double* x, double* dx, double t) const {
+        const int n = P.n;
+        const double* S = x;
+        const double* E = x + n;
+        const double* Pp = x + 2 * n;
+        const double* A = x + 3 * n;
+        const double* I = x + 4 * n;
+        const double* H = x + 5 * n;
+        const double* ICU = x + 6 * n;
+        double inf_pressure[MAX_AGE_CLASSES], lambda[MAX_AGE_CLASSES];  // reference: workspace_ members
+        for (int i = 0; i < n; ++i) lambda[i] = 0.0;  // :161-164
+        for (int i = 0; i < n; ++i) {  // :153-157
+            double total_inf = Pp[i] + A[i] + P.theta * I[i];
+            inf_pressure[i] = total_inf * P.h_infec[i] * inv_N[i];
+        }
+        for (int j = 0; j < n; ++j) {  // :166-174, column-major walk
+            const double inf_j = inf_pressure[j];
+            for (int i = 0; i < n; ++i) lambda[i] += P.M[j * n + i] * inf_j;
+        }
+        const double beta_eff = beta(t) * kappa(t);  // :176-178
+        for (int i = 0; i < n; ++i) lambda[i] *= beta_eff * P.a[i];  // :180-183
+        for (int i = 0; i < n; ++i) {  // :195-227
+            double lambda_val = std::max(0.0, lambda[i]);
+            double flow_SE = lambda_val * S[i];
+            double flow_EP = P.sigma * E[i];
+            double flow_P_out = P.gamma_p * Pp[i];
+            double flow_PA = P.p[i] * flow_P_out;
+            double flow_PI = flow_P_out - flow_PA;
+            double flow_IH = P.h[i] * I[i];
+            double flow_IR = P.gamma_I * I[i];
+            double flow_ID_community = P.d_community[i] * I[i];
+            double I_out = flow_IR + flow_IH + flow_ID_community;
+            double flow_H_ICU = P.icu[i] * H[i];
+            double H_out = P.gamma_H * H[i] + P.d_H[i] * H[i] + flow_H_ICU;
+            double ICU_out = (P.gamma_ICU + P.d_ICU[i]) * ICU[i];
+            dx[0 * n + i] = -flow_SE;
+            dx[1 * n + i] = flow_SE - flow_EP;
+            dx[2 * n + i] = flow_EP - flow_P_out;
+            dx[3 * n + i] = flow_PA - P.gamma_A * A[i];
+            dx[4 * n + i] = flow_PI - I_out;
+            dx[5 * n + i] = flow_IH - H_out;
+            dx[6 * n + i] = flow_H_ICU - ICU_out;
+            dx[7 * n + i] = P.gamma_A * A[i] + flow_IR + P.gamma_H * H[i] + P.gamma_ICU * ICU[i];
+            dx[8 * n + i] = P.d_H[i] * H[i] + P.d_ICU[i] * ICU[i] + flow_ID_community;
+            dx[9 * n + i] = flow_IH;
+            dx[10 * n + i] = flow_H_ICU;
+        }
+    }
+};
+
+// -----------------------------------------------------------------------------
+// Boost.Odeint restatement (third-party, version unpinned, NOT in the image).
+// Call sites: src/sir_age_structured/solvers/Dopri5SolverStrategy.cpp:28-37,
+//             src/sir_age_structured/solvers/CashKarpSolverStrategy.cpp:18-25.
+// Published algorithm restated:
+//   boost/numeric/odeint/integrate/detail/integrate_times.hpp (controlled tag)
+//   boost/numeric/odeint/stepper/controlled_runge_kutta.hpp
+//       (default_error_checker, default_step_adjuster, try_step for the
+//        explicit_error_stepper_tag and explicit_error_stepper_fsal_tag)
+//   boost/numeric/odeint/stepper/runge_kutta_dopri5.hpp (do_step_impl)
+//   boost/numeric/odeint/stepper/runge_kutta_cash_karp54.hpp + generic RK
+// -----------------------------------------------------------------------------
+enum Solver { DOPRI5 = 0, CASH_KARP54 = 1 };
+
+struct step_adjustment_error : std::runtime_error {
+    step_adjustment_error()
+        : std::runtime_error("Max number of iterations exceeded (500). A new step size was not found.") {}
+};
+
+struct StepStats {
+    long accepted = 0, rejected = 0, rhs_calls = 0;
+};
+
+using System = std::function<void(const double*, double*, double)>;
+
+// default_error_checker::error: max_i |xerr_i| / (eps_abs + eps_rel*(a_x*|x_i| + a_dxdt*dt*|dxdt_i|)),
+// a_x = a_dxdt = 1; norm_inf via max(init, |v|) starting from 0.
+inline double error_norm(const state_type& x_old, const state_type& dxdt_old, state_type& xerr,
+                         double dt, double eps_abs, double eps_rel) {
+    const double a_x = 1.0, a_dxdt_dt = 1.0 * dt;
+    double m = 0.0;
+    for (size_t i = 0; i < xerr.size(); ++i) {
+        xerr[i] = std::abs(xerr[i]) /
+                  (eps_abs + eps_rel * (a_x * std::abs(x_old[i]) + a_dxdt_dt * std::abs(dxdt_old[i])));
+        m = std::max(m, std::abs(xerr[i]));
+    }
+    return m;
+}
+// default_step_adjuster (max_dt = 0): order = 5, error_order = 4 for both steppers.
+inline double decrease_step(double dt, double error, int error_order) {
+    dt *= std::max(9.0 / 10.0 * std::pow(error, -1.0 / (error_order - 1)), 1.0 / 5.0);
+    return dt;
+}
+inline double increase_step(double dt, double error, int stepper_order) {
+    if (error < 0.5) {
+        error = std::max(std::pow(5.0, -static_cast<double>(stepper_order)), error);
+        dt *= 9.0 / 10.0 * std::pow(error, -1.0 / stepper_order);
+    }
+    return dt;
+}
+
+struct Dopri5Tableau {
+    // runge_kutta_dopri5::do_step_impl: every coefficient is a quotient of two
+    // doubles; the error weights dc_i are DIFFERENCES of two rounded quotients.
+    static constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    static constexpr double b21 = 1.0 / 5;
+    static constexpr double b31 = 3.0 / 40, b32 = 9.0 / 40;
+    static constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
+    static constexpr double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561,
+                            b54 = -212.0 / 729;
+    static constexpr double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247,
+                            b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+    static constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+                            c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    static constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
+                            dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
+                            dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+};
+
+struct CashKarpTableau {
+    // rk54_ck_coefficients_{a1..a5,b,db,c}
+    static constexpr double c2 = 1.0 / 5, c3 = 3.0 / 10, c4 = 3.0 / 5, c5 = 1.0, c6 = 7.0 / 8;
+    static constexpr double a21 = 1.0 / 5;
+    static constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
+    static constexpr double a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
+    static constexpr double a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
+    static constexpr double a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824,
+                            a64 = 44275.0 / 110592, a65 = 253.0 / 4096;
+    static constexpr double b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
+    static constexpr double db1 = 37.0 / 378 - 2825.0 / 27648, db3 = 250.0 / 621 - 18575.0 / 48384,
+                            db4 = 125.0 / 594 - 13525.0 / 55296, db5 = -277.0 / 14336,
+                            db6 = 512.0 / 1771 - 1.0 / 4;
+};
+
+// controlled_runge_kutta< runge_kutta_dopri5 > (FSAL) ------------------------
+struct ControlledDopri5 {
+    double eps_abs, eps_rel;
+    bool first_call = true;
+    state_type dxdt, xnew, dxdtnew, xerr, xtmp, k2, k3, k4, k5, k6;
+    StepStats* st;
+    ControlledDopri5(double a, double r, StepStats* s) : eps_abs(a), eps_rel(r), st(s) {}
+
+    // returns true on success; t and dt updated like try_step(sys, x, t, dt)
+    bool try_step(const System& sys, state_type& x, double& t, double& dt) {
+        const size_t m = x.size();
+        if (dxdt.size() != m || first_call) {  // try_step_v1: resize || m_first_call -> initialize
+            dxdt.resize(m);
+            sys(x.data(), dxdt.data(), t);
+            if (st) st->rhs_calls++;
+            first_call = false;
+        }
+        xnew.resize(m); dxdtnew.resize(m); xerr.resize(m); xtmp.resize(m);
+        k2.resize(m); k3.resize(m); k4.resize(m); k5.resize(m); k6.resize(m);
+        using T = Dopri5Tableau;
+        const double* k1 = dxdt.data();
+        {   // scale_sumN: t1 = a1*t2 + a2*t3 + ... evaluated left to right, a1 = 1.0
+            const double f1 = dt * T::b21;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i];
+            sys(xtmp.data(), k2.data(), t + dt * T::a2);
+        }
+        {
+            const double f1 = dt * T::b31, f2 = dt * T::b32;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i];
+            sys(xtmp.data(), k3.data(), t + dt * T::a3);
+        }
+        {
+            const double f1 = dt * T::b41, f2 = dt * T::b42, f3 = dt * T::b43;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i];
+            sys(xtmp.data(), k4.data(), t + dt * T::a4);
+        }
+        {
+            const double f1 = dt * T::b51, f2 = dt * T::b52, f3 = dt * T::b53, f4 = dt * T::b54;
+            for (size_t i = 0; i < m; ++i)
+                xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i] + f4 * k4[i];
+            sys(xtmp.data(), k5.data(), t + dt * T::a5);
+        }
+        {
+            const double f1 = dt * T::b61, f2 = dt * T::b62, f3 = dt * T::b63, f4 = dt * T::b64,
+                         f5 = dt * T::b65;
+            for (size_t i = 0; i < m; ++i)
+                xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i] + f4 * k4[i] + f5 * k5[i];
+            sys(xtmp.data(), k6.data(), t + dt);
+        }
+        {
+            const double f1 = dt * T::c1, f3 = dt * T::c3, f4 = dt * T::c4, f5 = dt * T::c5,
+                         f6 = dt * T::c6;
+            for (size_t i = 0; i < m; ++i)
+                xnew[i] = 1.0 * x[i] + f1 * k1[i] + f3 * k3[i] + f4 * k4[i] + f5 * k5[i] + f6 * k6[i];
+            sys(xnew.data(), dxdtnew.data(), t + dt);  // the new derivative (FSAL)
+        }
+        if (st) st->rhs_calls += 6;
+        {
+            const double e1 = dt * T::dc1, e3 = dt * T::dc3, e4 = dt * T::dc4, e5 = dt * T::dc5,
+                         e6 = dt * T::dc6, e7 = dt * T::dc7;
+            for (size_t i = 0; i < m; ++i)
+                xerr[i] = e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * dxdtnew[i];
+        }
+        const double max_rel_err = error_norm(x, dxdt, xerr, dt, eps_abs, eps_rel);
+        if (max_rel_err > 1.0) {
+            dt = decrease_step(dt, max_rel_err, 4);
+            if (st) st->rejected++;
+            return false;
+        }
+        t += dt;
+        dt = increase_step(dt, max_rel_err, 5);
+        x = xnew;        // copied only on success
+        dxdt = dxdtnew;
+        if (st) st->accepted++;
+        return true;
+    }
+};
+
+// controlled_runge_kutta< runge_kutta_cash_karp54 > (non-FSAL, generic RK) ----
+struct ControlledCashKarp {
+    double eps_abs, eps_rel;
+    state_type dxdt, xnew, xerr, xtmp, k2, k3, k4, k5, k6;
+    StepStats* st;
+    ControlledCashKarp(double a, double r, StepStats* s) : eps_abs(a), eps_rel(r), st(s) {}
+
+    bool try_step(const System& sys, state_type& x, double& t, double& dt) {
+        const size_t m = x.size();
+        dxdt.resize(m); xnew.resize(m); xerr.resize(m); xtmp.resize(m);
+        k2.resize(m); k3.resize(m); k4.resize(m); k5.resize(m); k6.resize(m);
+        sys(x.data(), dxdt.data(), t);  // try_step_v1: sys(x, m_dxdt, t) at EVERY attempt
+        using T = CashKarpTableau;
+        const double* k1 = dxdt.data();
+        // generic_rk_scale_sum: coefficients a[i]*dt; zero coefficients contribute +0.0
+        {
+            const double f1 = T::a21 * dt;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i];
+            sys(xtmp.data(), k2.data(), t + T::c2 * dt);
+        }
+        {
+            const double f1 = T::a31 * dt, f2 = T::a32 * dt;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i];
+            sys(xtmp.data(), k3.data(), t + T::c3 * dt);
+        }
+        {
+            const double f1 = T::a41 * dt, f2 = T::a42 * dt, f3 = T::a43 * dt;
+            for (size_t i = 0; i < m; ++i) xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i];
+            sys(xtmp.data(), k4.data(), t + T::c4 * dt);
+        }
+        {
+            const double f1 = T::a51 * dt, f2 = T::a52 * dt, f3 = T::a53 * dt, f4 = T::a54 * dt;
+            for (size_t i = 0; i < m; ++i)
+                xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i] + f4 * k4[i];
+            sys(xtmp.data(), k5.data(), t + T::c5 * dt);
+        }
+        {
+            const double f1 = T::a61 * dt, f2 = T::a62 * dt, f3 = T::a63 * dt, f4 = T::a64 * dt,
+                         f5 = T::a65 * dt;
+            for (size_t i = 0; i < m; ++i)
+                xtmp[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i] + f4 * k4[i] + f5 * k5[i];
+            sys(xtmp.data(), k6.data(), t + T::c6 * dt);
+        }
+        if (st) st->rhs_calls += 6;
+        {
+            const double f1 = T::b1 * dt, f2 = 0.0 * dt, f3 = T::b3 * dt, f4 = T::b4 * dt,
+                         f5 = 0.0 * dt, f6 = T::b6 * dt;
+            for (size_t i = 0; i < m; ++i)
+                xnew[i] = 1.0 * x[i] + f1 * k1[i] + f2 * k2[i] + f3 * k3[i] + f4 * k4[i] + f5 * k5[i] +
+                          f6 * k6[i];
+        }
+        {
+            const double e1 = T::db1 * dt, e2 = 0.0 * dt, e3 = T::db3 * dt, e4 = T::db4 * dt,
+                         e5 = T::db5 * dt, e6 = T::db6 * dt;
+            for (size_t i = 0; i < m; ++i)
+                xerr[i] = e1 * k1[i] + e2 * k2[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i];
+        }
+        const double max_rel_err = error_norm(x, dxdt, xerr, dt, eps_abs, eps_rel);
+        if (max_rel_err > 1.0) {
+            dt = decrease_step(dt, max_rel_err, 4);
+            if (st) st->rejected++;
+            return false;
+        }
+        t += dt;
+        dt = increase_step(dt, max_rel_err, 5);
+        x = xnew;
+        if (st) st->accepted++;
+        return true;
+    }
+};
+
+// integrate_times( controlled stepper, sys, x, times_begin, times_end, dt, obs )
+template <class Stepper>
+inline size_t integrate_times(Stepper& stepper, const System& sys, state_type& x,
+                              const std::vector<double>& times, double dt,
+                              const std::function<void(const state_type&, double)>& obs) {
+    size_t steps = 0;
+    int fails = 0;  // failed_step_checker, max 500
+    auto it = times.begin();
+    const auto end = times.end();
+    if (it == end) return 0;
+    while (true) {
+        double current_time = *it++;
+        obs(x, current_time);
+        if (it == end) break;
+        // less_with_sign(t1, t2, dt>0): t2 - t1 > epsilon
+        while ((*it - current_time) > std::numeric_limits<double>::epsilon()) {
+            double current_dt = std::min(dt, *it - current_time);  // min_abs, dt > 0
+            if (stepper.try_step(sys, x, current_time, current_dt)) {
+                ++steps;
+                fails = 0;
+                dt = std::max(dt, current_dt);  // max_abs
+            } else {
+                if (fails++ >= 500) throw step_adjustment_error();
+                dt = current_dt;
+            }
+        }
+    }
+    return steps;
+}
+
+// -----------------------------------------------------------------------------
+// Simulator::run grid validation (src/sir_age_structured/Simulator.cpp:60-150)
+// -----------------------------------------------------------------------------
+struct SimulationResult {
+    std::vector<double> time_points;
+    std::vector<state_type> solution;
+};
+
+inline SimulationResult simulate(const Model& model, const state_type& init,
+                                 const std::vector<double>& times, Solver solver, double dt_hint,
+                                 double abs_err, double rel_err, StepStats* st = nullptr) {
+    if (static_cast<int>(init.size()) != NUM_COMPARTMENTS * model.P.n)
+        throw std::invalid_argument("Simulator::run: initial state size mismatch");
+    if (times.empty()) throw std::invalid_argument("Simulator::run: empty output time points");
+    for (size_t i = 1; i < times.size(); ++i)
+        if (times[i] <= times[i - 1])
+            throw std::invalid_argument("Simulator::run: time points must be strictly increasing");
+    SimulationResult res;
+    state_type x = init;
+    System sys = [&model](const double* xs, double* dx, double t) { model.rhs(xs, dx, t); };
+    auto obs = [&res](const state_type& s, double t) {
+        res.time_points.push_back(t);
+        res.solution.push_back(s);
+    };
+    if (solver == DOPRI5) {
+        ControlledDopri5 stp(abs_err, rel_err, st);
+        integrate_times(stp, sys, x, times, dt_hint, obs);
+    } else {
+        ControlledCashKarp stp(abs_err, rel_err, st);
+        integrate_times(stp, sys, x, times, dt_hint, obs);
+    }
+    return res;
+}
+
+// -----------------------------------------------------------------------------
+// Poisson log-likelihood of one stream, serial summation order.
+// src/model/objectives/SEPAIHRDObjectiveFunction.cpp:241-279.  The reference
+// wraps the row loop in an OpenMP reduction when rows*cols >= 256; its result
+// then depends on the thread count, so parity is defined against this serial
+// (1-thread) order.  sim, obs: row-major rows x cols.
+// -----------------------------------------------------------------------------
+inline double poisson_loglik(const double* sim, const double* obs, int rows, int cols) {
+    const double epsilon = 1e-10;
+    double log_likelihood = 0.0;
+    for (int i = 0; i < rows; ++i) {
+        double row_sum = 0.0;
+        for (int j = 0; j < cols; ++j) {
+            const double o = obs[i * cols + j];
+            if (o >= 0.0 && std::isfinite(o)) {
+                double s = sim[i * cols + j];
+                if (s < 0.0) s = 0.0;
+                s += epsilon;
+                row_sum += (o * std::log(s) - s);
+            }
+        }
+        log_likelihood += row_sum;
+    }
+    return log_likelihood;
+}
+
+// -----------------------------------------------------------------------------
+// Parameter manager: src/model/parameters/SEPAIHRDParameterManager.cpp
+// -----------------------------------------------------------------------------
+enum ConstraintMode { OPTIMIZATION_CLAMP = 0, MCMC_REFLECT = 1 };
+
+// :302-313
+inline double reflect_bound(double value, double minb, double maxb) {
+    if (minb >= maxb) return minb;
+    double width = maxb - minb;
+    double y = std::fmod(value - minb, 2.0 * width);
+    if (y < 0) y += 2.0 * width;
+    if (y <= width) return minb + y;
+    return maxb - (y - width);
+}
+
+struct ParameterManager {
+    std::vector<std::string> names;
+    std::map<std::string, double> sigmas;
+    std::map<std::string, std::pair<double, double>> bounds;
+    // names of the NPI strategy's calibratable (after-baseline) values, in order
+    // (PieceWiseConstantNPIStrategy.cpp:55-61: default "kappa_<i+2>")
+    std::vector<std::string> npi_names;
+    ConstraintMode mode = OPTIMIZATION_CLAMP;
+
+    // :315-347
+    std::vector<double> applyConstraints(const std::vector<double>& p) const {
+        if (p.size() != names.size()) throw std::invalid_argument("applyConstraints: size mismatch");
+        std::vector<double> c = p;
+        for (size_t i = 0; i < names.size(); ++i) {
+            auto it = bounds.find(names[i]);
+            if (it != bounds.end()) {
+                double minb = it->second.first, maxb = it->second.second;
+                if (minb > maxb) std::swap(minb, maxb);
+                if (mode == OPTIMIZATION_CLAMP) c[i] = std::min(std::max(p[i], minb), maxb);
+                else c[i] = reflect_bound(p[i], minb, maxb);
+            } else {
+                if (mode == OPTIMIZATION_CLAMP) c[i] = std::max(0.0, p[i]);
+                else c[i] = std::abs(p[i]);
+            }
+        }
+        return c;
+    }
+
+    static bool starts(const std::string& s, const char* pre) { return s.rfind(pre, 0) == 0; }
+
+    // :164-287 updateModelParameters(theta, target_model).  Throws on the same
+    // conditions the reference throws on (the objective maps any throw to lowest()).
+    void updateModelParameters(const std::vector<double>& theta, Model& model) const {
+        if (theta.size() != names.size()) throw std::invalid_argument("size mismatch");
+        std::vector<double> c = applyConstraints(theta);
+        Params up = model.P;
+        std::vector<double> npi_vals(up.kappa_values.begin() + 1, up.kappa_values.end());
+        bool npi_update = false;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const std::string& name = names[i];
+            const double value = c[i];
+            if (name == "beta") up.beta = value;
+            else if (starts(name, "beta_")) {
+                size_t idx = std::stoul(name.substr(5)) - 1;
+                if (idx < up.beta_values.size()) up.beta_values[idx] = value;
+                else throw std::invalid_argument("Beta index out of range: " + name);
+            }
+            else if (name == "theta") up.theta = value;
+            else if (name == "sigma") up.sigma = value;
+            else if (name == "gamma_p") up.gamma_p = value;
+            else if (name == "gamma_A") up.gamma_A = value;
+            else if (name == "gamma_I") up.gamma_I = value;
+            else if (name == "gamma_H") up.gamma_H = value;
+            else if (name == "gamma_ICU") up.gamma_ICU = value;
+            else if (starts(name, "a_")) up.a.at(std::stoul(name.substr(2))) = value;
+            else if (starts(name, "h_infec_")) up.h_infec.at(std::stoul(name.substr(8))) = value;
+            else if (starts(name, "p_")) up.p.at(std::stoul(name.substr(2))) = value;
+            else if (starts(name, "h_")) up.h.at(std::stoul(name.substr(2))) = value;
+            else if (starts(name, "icu_")) up.icu.at(std::stoul(name.substr(4))) = value;
+            else if (starts(name, "d_H_")) up.d_H.at(std::stoul(name.substr(4))) = value;
+            else if (starts(name, "d_ICU_")) up.d_ICU.at(std::stoul(name.substr(6))) = value;
+            else if (starts(name, "d_community_")) {
+                size_t idx = std::stoul(name.substr(12));
+                if (up.d_community.empty()) up.d_community.assign(model.P.n, 0.0);
+                if (idx < up.d_community.size()) up.d_community[idx] = value;
+            }
+            else if (name == "seed_exposed") up.seed_exposed = value;
+            else if (name == "runup_days") up.runup_days = value;
+            else if (name == "E0_multiplier") up.E0_multiplier = value;
+            else if (name == "P0_multiplier") up.P0_multiplier = value;
+            else if (name == "A0_multiplier") up.A0_multiplier = value;
+            else if (name == "I0_multiplier") up.I0_multiplier = value;
+            else if (name == "H0_multiplier") up.H0_multiplier = value;
+            else if (name == "ICU0_multiplier") up.ICU0_multiplier = value;
+            else if (name == "R0_multiplier") up.R0_multiplier = value;
+            else if (name == "D0_multiplier") up.D0_multiplier = value;
+            else if (starts(name, "kappa_")) {
+                for (size_t k = 0; k < npi_names.size(); ++k)
+                    if (npi_names[k] == name) { npi_vals[k] = value; npi_update = true; break; }
+            }
+            // unknown names: reference prints a warning and continues (:264-266)
+        }
+        if (npi_update) {
+            // setCalibratableValues (PieceWiseConstantNPIStrategy.cpp:228-262): negative -> throw
+            for (double v : npi_vals)
+                if (v < 0.0) throw std::invalid_argument("All NPI kappa values must be non-negative.");
+            for (size_t k = 0; k < npi_vals.size(); ++k) up.kappa_values[k + 1] = npi_vals[k];
+        }
+        model.set(up);
+    }
+};
+
+// -----------------------------------------------------------------------------
+// The objective: src/model/objectives/SEPAIHRDObjectiveFunction.cpp:22-50,62-235
+// obs_*: row-major num_obs_rows x n.
+// -----------------------------------------------------------------------------
+struct Problem {
+    Params base;
+    ParameterManager pm;
+    std::vector<double> time_points;
+    state_type initial_state;
+    int num_obs_rows = 0;
+    std::vector<double> obs_H, obs_ICU, obs_D;
+    Solver solver = DOPRI5;
+    double abs_err = 1e-6, rel_err = 1e-6, dt_hint = 1.0;
+};
+
+struct EvalInfo {
+    StepStats steps;
+    int status = 0;  // 0 ok, 1 = returned lowest(), 2 = SimulationException would propagate
+    double ll_hosp = 0, ll_icu = 0, ll_deaths = 0;
+};
+
+inline double objective(const Problem& pb, const std::vector<double>& theta, EvalInfo* info = nullptr,
+                        std::vector<double>* traj = nullptr) {
+    const double LOWEST = std::numeric_limits<double>::lowest();
+    EvalInfo local;
+    EvalInfo& inf = info ? *info : local;
+    inf = EvalInfo{};
+    const std::vector<double>& tp = pb.time_points;
+    // ctor :39-46
+    int runup_offset = 0;
+    for (size_t i = 0; i < tp.size(); ++i)
+        if (tp[i] >= 0.0) { runup_offset = static_cast<int>(i); break; }
+    const int num_obs_points = static_cast<int>(tp.size()) - runup_offset;
+    if (tp.empty()) { inf.status = 1; return LOWEST; }  // :110-112
+
+    Model model(pb.base);
+    const int n = model.P.n;
+    double total_pop = 0.0;
+    for (int i = 0; i < n; ++i) total_pop += model.P.N[i];  // Eigen sum(): sequential for small n
+    std::vector<double> age_fraction(n, 0.0);
+    if (total_pop > 0.0)
+        for (int i = 0; i < n; ++i) age_fraction[i] = model.P.N[i] / total_pop;
+
+    try {
+        pb.pm.updateModelParameters(theta, model);  // :117-122
+    } catch (...) { inf.status = 1; return LOWEST; }
+
+    state_type init = pb.initial_state;  // :126
+    const double runup_days = model.P.runup_days, seed_exposed = model.P.seed_exposed;
+    if (runup_days > 0 && seed_exposed > 0) {  // :131-143
+        for (int i = 0; i < n; ++i) {
+            init[i + n] = seed_exposed * age_fraction[i];
+            for (int c = 2; c <= 10; ++c) init[i + c * n] = 0.0;
+        }
+    } else {  // :145-152
+        const double mult[8] = {model.P.E0_multiplier, model.P.P0_multiplier, model.P.A0_multiplier,
+                                model.P.I0_multiplier, model.P.H0_multiplier, model.P.ICU0_multiplier,
+                                model.P.R0_multiplier, model.P.D0_multiplier};
+        for (int c = 1; c <= 8; ++c)
+            for (int i = 0; i < n; ++i) init[c * n + i] *= mult[c - 1];
+    }
+    for (int i = 0; i < n; ++i) {  // :155-163
+        double sum = 0;
+        for (int j = 1; j < NUM_POPULATION_COMPARTMENTS; ++j) sum += init[j * n + i];
+        if (sum > model.P.N[i]) { inf.status = 1; return LOWEST; }
+        init[i] = model.P.N[i] - sum;
+    }
+
+    SimulationResult res;
+    try {
+        res = simulate(model, init, tp, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &inf.steps);
+    } catch (const step_adjustment_error&) {
+        inf.status = 2;  // SimulationException propagates out of calculate() (no try/catch at :165)
+        return LOWEST;
+    }
+    const size_t T = tp.size();
+    if (traj) {
+        traj->resize(T * NUM_COMPARTMENTS * n);
+        for (size_t k = 0; k < T; ++k)
+            std::copy(res.solution[k].begin(), res.solution[k].end(),
+                      traj->begin() + k * NUM_COMPARTMENTS * n);
+    }
+    if (num_obs_points != pb.num_obs_rows) { inf.status = 1; return LOWEST; }  // :176-178
+
+    // :191-215 daily incidence from the cumulative compartments D (8n), CumH (9n), CumICU (10n)
+    std::vector<double> sim_hosp(T * n), sim_icu(T * n), sim_deaths(T * n);
+    auto diff = [&](std::vector<double>& out, int comp) {
+        for (int i = 0; i < n; ++i) out[i] = res.solution[0][comp * n + i] - init[comp * n + i];
+        for (size_t k = 1; k < T; ++k)
+            for (int i = 0; i < n; ++i)
+                out[k * n + i] = res.solution[k][comp * n + i] - res.solution[k - 1][comp * n + i];
+        for (double& v : out) v = std::max(v, 0.0);  // cwiseMax(0.0)
+    };
+    diff(sim_hosp, 9);
+    diff(sim_icu, 10);
+    diff(sim_deaths, 8);
+    // :218-225 bottom num_obs_points rows
+    const size_t off = static_cast<size_t>(runup_offset) * n;
+    inf.ll_hosp = poisson_loglik(sim_hosp.data() + off, pb.obs_H.data(), num_obs_points, n);
+    inf.ll_icu = poisson_loglik(sim_icu.data() + off, pb.obs_ICU.data(), num_obs_points, n);
+    inf.ll_deaths = poisson_loglik(sim_deaths.data() + off, pb.obs_D.data(), num_obs_points, n);
+    double total = inf.ll_hosp + inf.ll_icu + inf.ll_deaths;
+    if (std::isnan(total) || std::isinf(total)) { total = LOWEST; inf.status = 1; }  // :227
+    return total;
+}
+
+// -----------------------------------------------------------------------------
+// SimulationCache::computeHash  (src/sir_age_structured/caching/SimulationCache.cpp:12-19,35-52)
+// -----------------------------------------------------------------------------
+inline uint64_t mix_hash(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+inline uint64_t cache_hash(const double* p, int size) {
+    uint64_t seed = 0;
+    for (int i = 0; i < size; ++i) {
+        long long q = static_cast<long long>(p[i] * 1e8 + 0.5);
+        uint64_t k = static_cast<uint64_t>(q);
+        seed ^= mix_hash(k) + 0x9e3779b9ULL + (seed << 6) + (seed >> 2);
+    }
+    return seed;
+}
+
+// -----------------------------------------------------------------------------
+// Synthetic parameter draws: the reference benchmark's jitter protocol
+// (src/model/sepaihrd_objective_benchmark_main.cpp:412-413,452-460), one
+// mt19937(seed) + one persistent normal_distribution per chain.
+// -----------------------------------------------------------------------------
+inline std::vector<double> jitter_draw(const ParameterManager& pm, const std::vector<double>& base,
+                                       uint32_t seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    std::vector<double> cand(base.size());
+    for (size_t i = 0; i < base.size(); ++i) {
+        const double s = pm.sigmas.at(pm.names[i]);
+        cand[i] = base[i] + s * normal(rng);
+    }
+    return pm.applyConstraints(cand);
+}
+
+// -----------------------------------------------------------------------------
+// Adaptive-Metropolis sampler restated with plain loops.
+// src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:65-412.
+// A seed replaces the reference's std::random_device (:20-23) -- a build-side
+// addition.  Eigen::LLT is replaced by a textbook
+// lower Cholesky; Eigen's blocked evaluation order is not reproduced
+// (parity unpinned for those bits).
+// -----------------------------------------------------------------------------
+struct MHSettings {
+    int iterations = 10000, burn_in = 1000, adaptation_period = 100, thinning = 1;
+    double regularization_epsilon = 1e-6, target_acceptance_rate = 0.234;
+    bool adapt_scale = true;
+};
+
+struct MHResult {
+    std::vector<double> best;
+    double best_value = -std::numeric_limits<double>::infinity();
+    std::vector<std::vector<double>> samples;
+    std::vector<double> sample_values;
+    int accepted = 0;
+    double final_scale = 1.0;
+    std::vector<double> final_cov;  // P x P row-major
+    std::vector<unsigned char> accept_trace;
+};
+
+inline bool cholesky_lower(const std::vector<double>& A, int P, std::vector<double>& L) {
+    L.assign(static_cast<size_t>(P) * P, 0.0);
+    for (int j = 0; j < P; ++j) {
+        double d = A[j * P + j];
+        for (int k = 0; k < j; ++k) d -= L[j * P + k] * L[j * P + k];
+        if (!(d > 0.0)) return false;
+        const double ljj = std::sqrt(d);
+        L[j * P + j] = ljj;
+        for (int i = j + 1; i < P; ++i) {
+            double s = A[i * P + j];
+            for (int k = 0; k < j; ++k) s -= L[i * P + k] * L[j * P + k];
+            L[i * P + j] = s / ljj;
+        }
+    }
+    return true;
+}
+
+using Objective = std::function<double(const std::vector<double>&)>;
+
+inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<double>& x0,
+                                    const Objective& objective_fn, ParameterManager& pm,
+                                    uint32_t seed) {
+    pm.mode = MCMC_REFLECT;  // :207-209
+    const int P = static_cast<int>(x0.size());
+    std::mt19937 gen(seed);
+    auto safe_eval = [&](const std::vector<double>& p) {  // :65-74
+        try {
+            double v = objective_fn(p);
+            if (std::isnan(v) || std::isinf(v)) return -1e18;
+            return v;
+        } catch (...) { return -1e18; }
+    };
+    MHResult r;
+    std::vector<double> cur = x0;
+    std::vector<double> cov(static_cast<size_t>(P) * P, 0.0);
+    for (int i = 0; i < P; ++i) {  // :226-233
+        double s = pm.sigmas.at(pm.names[i]);
+        cov[i * P + i] = (s > 0 ? s * s : 1e-6);
+    }
+    const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
+    for (double& v : cov) v *= scaling_factor;
+    for (int i = 0; i < P; ++i) cov[i * P + i] += cfg.regularization_epsilon;  // :237
+    std::vector<double> L;
+    if (!cholesky_lower(cov, P, L)) {  // :240-246
+        L.assign(static_cast<size_t>(P) * P, 0.0);
+        for (int i = 0; i < P; ++i) L[i * P + i] = 0.1;
+    }
+    std::vector<double> running_mean = x0;
+    double log_scale = 0.0, global_scale = 1.0;
+    double cur_lp = safe_eval(cur);
+    std::vector<std::vector<double>> history;
+    history.reserve(cfg.iterations);
+    history.push_back(cur);
+    r.samples.push_back(cur);
+    r.sample_values.push_back(cur_lp);
+    r.best = cur;
+    r.best_value = cur_lp;
+    std::deque<int> recent;
+    int emergency = 0;
+    std::uniform_real_distribution<double> u_dist(0.0, 1.0);
+    r.accept_trace.reserve(cfg.iterations);
+
+    for (int t = 1; t < cfg.iterations; ++t) {
+        if (t > cfg.burn_in) {
+            {   // updateCovarianceRank1 :154-166
+                const std::vector<double>& ns = history.back();
+                const double gamma = 10.0 / (t + 100.0);
+                std::vector<double> diff(P);
+                for (int i = 0; i < P; ++i) diff[i] = ns[i] - running_mean[i];
+                for (int i = 0; i < P; ++i) running_mean[i] += gamma * diff[i];
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j)
+                        cov[i * P + j] = (1.0 - gamma) * cov[i * P + j] + gamma * (diff[i] * diff[j]);
+            }
+            if (t % cfg.adaptation_period == 0) {
+                // recomputeFullCovariance :168-199
+                if (history.size() >= static_cast<size_t>(P) + 10) {
+                    std::vector<double> mean(P, 0.0);
+                    for (const auto& v : history)
+                        for (int i = 0; i < P; ++i) mean[i] += v[i];
+                    for (int i = 0; i < P; ++i) mean[i] /= static_cast<double>(history.size());
+                    running_mean = mean;
+                    std::vector<double> c(static_cast<size_t>(P) * P, 0.0);
+                    for (const auto& v : history)
+                        for (int i = 0; i < P; ++i) {
+                            const double di = v[i] - mean[i];
+                            for (int j = 0; j < P; ++j) c[i * P + j] += di * (v[j] - mean[j]);
+                        }
+                    const double denom = double(history.size() - 1);
+                    for (int i = 0; i < P; ++i)
+                        for (int j = 0; j < P; ++j)
+                            cov[i * P + j] = scaling_factor * (c[i * P + j] / denom) +
+                                             (i == j ? cfg.regularization_epsilon : 0.0);
+                    std::vector<double> Ltry;
+                    if (cholesky_lower(cov, P, Ltry)) L = Ltry;
+                }
+                // :295-300  epsilon added again before the LLT that is actually kept
+                std::vector<double> stable = cov;
+                for (int i = 0; i < P; ++i) stable[i * P + i] += cfg.regularization_epsilon;
+                std::vector<double> Ltry;
+                if (cholesky_lower(stable, P, Ltry)) L = Ltry;
+            }
+        }
+        // generateProposal :91-102 (fresh normal_distribution per call)
+        std::vector<double> z(P);
+        {
+            std::normal_distribution<double> dist(0.0, 1.0);
+            for (int i = 0; i < P; ++i) z[i] = dist(gen);
+        }
+        std::vector<double> raw(P);
+        for (int i = 0; i < P; ++i) {
+            double s = 0.0;
+            for (int j = 0; j <= i; ++j) s += L[i * P + j] * z[j];
+            raw[i] = cur[i] + global_scale * s;
+        }
+        std::vector<double> prop = pm.applyConstraints(raw);  // :309
+        const double prop_lp = safe_eval(prop);               // :312
+        const double log_ratio = prop_lp - cur_lp;
+        bool accept = false;
+        if (log_ratio >= 0.0) accept = true;
+        else if (std::log(u_dist(gen)) < log_ratio) accept = true;  // U drawn only here (:327)
+        if (accept) {
+            cur = prop;
+            cur_lp = prop_lp;
+            r.accepted++;
+            if (cur_lp > r.best_value) { r.best_value = cur_lp; r.best = cur; }
+        }
+        r.accept_trace.push_back(accept ? 1 : 0);
+        if (cfg.adapt_scale) {  // adaptGlobalScale :104-152
+            recent.push_back(accept ? 1 : 0);
+            if (recent.size() > 1000) recent.pop_front();
+            double rate = 0.0;
+            if (!recent.empty()) {
+                int sum = 0;
+                for (int a : recent) sum += a;
+                rate = static_cast<double>(sum) / recent.size();
+            }
+            if (recent.size() >= 1000 && rate < 0.001) {
+                log_scale -= 0.7;
+                emergency++;
+            } else if (rate < 0.02 && recent.size() >= 500) {
+                double g = 5.0 / std::sqrt(static_cast<double>(t) + 1.0);
+                g = std::min(g, 0.3);
+                log_scale += g * (0.0 - cfg.target_acceptance_rate);
+            } else {
+                double g = 1.0 / std::sqrt(static_cast<double>(t) + 1.0);
+                g = std::min(g, 0.1);
+                log_scale += g * ((accept ? 1.0 : 0.0) - cfg.target_acceptance_rate);
+            }
+            if (global_scale <= 0.011 && rate > 0.15 && rate < 0.30) log_scale += 0.01;
+            log_scale = std::max(std::min(log_scale, 2.3), -6.9);
+            global_scale = std::exp(log_scale);
+        }
+        history.push_back(cur);
+        if (t % cfg.thinning == 0) {
+            r.samples.push_back(cur);
+            r.sample_values.push_back(cur_lp);
+        }
+    }
+    (void)emergency;
+    r.final_scale = global_scale;
+    r.final_cov = cov;
+    return r;
+}
+
+}  // namespace oracle

@@ -1,0 +1,146 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (fp64):
+  * strict arithmetic: the kernel performs the oracle's operation sequence; the only
+    differences are libm (pow in the step-size controller after a rejected step, log in
+    the likelihood).  Accepted/rejected step counts must be identical, trajectories agree
+    to 1e-9 relative (north-star bar: 1e-6), log-likelihood to 1e-10 relative.
+  * fma arithmetic: contraction changes roundings; north-star bar 1e-6 relative on states.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_STATE_BAR = 1e-6  # BASELINE.json north_star: trajectory states within 1e-6 relative
+
+
+def rel_state_err(a, b, pb):
+    """relative error per state entry, scaled by max(|ref|, abs_tol-level floor of 1 person)"""
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+
+
+@pytest.fixture(scope="module")
+def draws(mm, oracle_py):
+    def make(pb, B, seed0=1):
+        return oracle_py.Oracle(pb).jitter_draws(pb.base_theta, seed0, B, mode=1)
+    return make
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("fixture_name", ["shipped", "ref_fixture", "synth400"])
+def test_strict_matches_oracle(mm, oracle_py, request, fixture_name, solver, draws):
+    pb = request.getfixturevalue(fixture_name)
+    pb.solver = solver
+    pb.arith = mm.ARITH_STRICT
+    B = 37 if fixture_name != "ref_fixture" else 21  # ragged: not a multiple of 16 chains/wave
+    if fixture_name == "ref_fixture":
+        rs = np.random.RandomState(5)
+        lo, hi, _ = pb.bounds_arrays()
+        theta = lo + (hi - lo) * rs.uniform(0, 1, (B, pb.n_params))
+        theta[0] = pb.base_theta
+    else:
+        theta = draws(pb, B)
+        theta[0] = pb.base_theta
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    hip = mm.HipObjective(pb)
+    got = hip.eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"])
+    assert np.array_equal(got["n_accept"], ref["n_accept"]), (got["n_accept"], ref["n_accept"])
+    assert np.array_equal(got["n_reject"], ref["n_reject"])
+    err = rel_state_err(got["traj"], ref["traj"], pb).max()
+    assert err < 1e-9, err
+    assert err < REL_STATE_BAR
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+    np.testing.assert_allclose(got["ll_parts"], ref["ll_parts"], rtol=1e-10)
+    # likelihood-only launch gives the same numbers as the trajectory launch
+    again = hip.eval_batch(theta)
+    assert np.array_equal(again["loglik"], got["loglik"])
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_fma_within_north_star_tolerance(mm, oracle_py, synth400, solver, draws):
+    pb = synth400
+    pb.solver = solver
+    pb.arith = mm.ARITH_FMA
+    theta = draws(pb, 64)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"])
+    err = rel_state_err(got["traj"], ref["traj"], pb).max()
+    assert err < REL_STATE_BAR, err
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-7)
+    same_steps = np.mean((got["n_accept"] == ref["n_accept"]) & (got["n_reject"] == ref["n_reject"]))
+    assert same_steps > 0.9
+
+
+def test_golden_highprec(mm, golden, shipped):
+    """HIP path against the independent high-precision answers (solver-tolerance limited)."""
+    g = golden["shipped"]
+    got = mm.HipObjective(shipped).eval_batch(np.array(g["theta"])[None, :], want_traj=True)
+    assert abs(got["loglik"][0] - g["loglik"]) / abs(g["loglik"]) < 5e-5
+    st = got["traj"][0][g["time_index"]]
+    gs = np.array(g["states"])
+    assert (np.abs(st - gs) / (np.abs(gs) + 1.0)).max() < 1e-3
+
+
+def test_failure_sentinels(mm, oracle_py, shipped):
+    """calculate() returns lowest() for a seed larger than the population (S < 0 branch,
+    SEPAIHRDObjectiveFunction.cpp:155-163) -- same chain indices flagged as the oracle."""
+    pb = shipped
+    pb.bounds = dict(pb.bounds)
+    pb.bounds["seed_exposed"] = (5.0, 1e9)
+    theta = np.tile(pb.base_theta, (5, 1))
+    k = pb.param_names.index("seed_exposed")
+    theta[1, k] = 9e8
+    theta[3, k] = 2e8
+    ref = oracle_py.Oracle(pb).eval_batch(theta)
+    got = mm.HipObjective(pb).eval_batch(theta)
+    assert np.array_equal(got["status"], ref["status"])
+    assert got["status"].tolist() == [0, 1, 0, 1, 0]
+    assert got["loglik"][1] == mm.LOWEST and got["loglik"][3] == mm.LOWEST
+    np.testing.assert_allclose(got["loglik"][[0, 2, 4]], ref["loglik"][[0, 2, 4]], rtol=1e-10)
+
+
+def test_nan_observations_skipped_and_clamp_mode(mm, oracle_py, ref_fixture):
+    pb = ref_fixture
+    pb.obs_H = pb.obs_H.copy()
+    pb.obs_H[3, 1] = np.nan
+    pb.obs_H[7, 2] = -1.0
+    rs = np.random.RandomState(11)
+    lo, hi, _ = pb.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(-0.3, 1.3, (16, pb.n_params))  # outside bounds: clamp acts
+    ref = oracle_py.Oracle(pb).eval_batch(theta)
+    got = mm.HipObjective(pb).eval_batch(theta)
+    assert np.all(np.isfinite(got["loglik"]))
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+
+
+def test_device_pointer_entry_point(mm, oracle_py, synth400, draws):
+    import torch
+    pb = synth400
+    theta = draws(pb, 100)
+    hip = mm.HipObjective(pb)
+    host = hip.eval_batch(theta)
+    d_theta = torch.from_numpy(theta).cuda()
+    d_ll = torch.empty(100, dtype=torch.float64, device="cuda")
+    d_st = torch.empty(100, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    hip.eval_batch_device(d_theta, d_ll, d_status=d_st, stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ll.cpu().numpy(), host["loglik"])
+    assert np.array_equal(d_st.cpu().numpy(), host["status"])
+
+
+def test_full_size_properties(mm, synth400, draws):
+    """BASELINE config 2 size (4096 chains, 400 days): size-independent properties --
+    duplicated chains give bit-identical results wherever they sit in the batch, every
+    chain finishes, step counts are >= the 400 daily intervals."""
+    pb = synth400
+    base = draws(pb, 512)
+    theta = np.tile(base, (8, 1))
+    got = mm.HipObjective(pb).eval_batch(theta)
+    ll = got["loglik"].reshape(8, 512)
+    assert np.all(got["status"] == 0)
+    assert np.all(ll == ll[0:1])
+    assert np.all(got["n_accept"] >= 400)
