@@ -141,9 +141,14 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
         }
 
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        set_err(err, errlen, "no HIP device available (this library has no CPU fallback)");
-        return nullptr;
+    {
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            set_err(err, errlen, std::string("no HIP device available (this library has no CPU fallback): "
+                                             "hipGetDeviceCount -> ") + hipGetErrorString(e) + ", count " +
+                                     std::to_string(ndev));
+            return nullptr;
+        }
     }
     if (device < 0) {
         if (hipGetDevice(&device) != hipSuccess) { set_err(err, errlen, "hipGetDevice failed"); return nullptr; }

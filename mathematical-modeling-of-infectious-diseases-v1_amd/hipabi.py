@@ -69,6 +69,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64 and a second copy (the system ROCm the library was linked against) cannot
+    # open the device once the first has.  Importing torch FIRST makes the dynamic linker resolve
+    # our NEEDED libamdhip64.so.7 to the already-loaded copy (same SONAME), so torch tensors,
+    # torch streams and these kernels share one runtime.  Without torch (C++ hosts) the system
+    # runtime from the library's RUNPATH is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
