@@ -35,7 +35,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=4096, help="chains per GPU per step")
     ap.add_argument("--solver", choices=["dopri5", "cashkarp"], default="dopri5")
-    ap.add_argument("--arith", choices=["strict", "fma"], default="strict")
+    ap.add_argument("--arith", choices=["strict", "fma"], default="fma",
+                    help="fma: mul+add contraction on (production mode, parity-tested to the 1e-6 north-star "
+                         "tolerance); strict: the CPU build's operation sequence (bit-level parity mode)")
     ap.add_argument("--problem", default="synth_400d_n4.json")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
@@ -61,22 +63,27 @@ def cpu_baseline(pb, theta, budget_s):
     import oracle_py
     orc = oracle_py.Oracle(pb)
     cores = oracle_py.load().oracle_num_threads()
-    probe = min(len(theta), 4 * cores)
+    # single thread first: ~2 s
     t0 = time.perf_counter()
-    orc.eval_batch(theta[:probe], nthreads=cores)
-    t_probe = time.perf_counter() - t0
-    n_eval = int(max(probe, min(len(theta), budget_s / max(t_probe / probe, 1e-9))))
+    orc.eval_batch(theta[:8], nthreads=1)
+    per_eval_1t = (time.perf_counter() - t0) / 8
+    n1 = int(max(8, min(len(theta), 2.0 / per_eval_1t)))
     t0 = time.perf_counter()
-    orc.eval_batch(theta[:n_eval], nthreads=cores)
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    n1 = max(1, min(n_eval, int(2.0 / max(t_probe / probe * cores, 1e-9)) or 1))
     orc.eval_batch(theta[:n1], nthreads=1)
     dt1 = time.perf_counter() - t0
+    # all cores: repeat the batch until ~budget_s of wall time has been spent
+    orc.eval_batch(theta[:min(len(theta), 4 * cores)], nthreads=cores)  # thread-pool warm-up
+    n_eval, dt = 0, 0.0
+    while dt < budget_s and n_eval < 400 * len(theta):
+        t0 = time.perf_counter()
+        orc.eval_batch(theta, nthreads=cores)
+        dt += time.perf_counter() - t0
+        n_eval += len(theta)
     return {
         "value": n_eval / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-        "sample": f"{n_eval} of the same jittered draws, oracle/liboracle.so (g++ -O3, no -march=native, "
-                  f"no FMA), OpenMP over chains, {cores} threads; 1 thread: {n1 / dt1:.1f} evals/s",
+        "sample": f"{n_eval} evaluations ({n_eval // len(theta)} passes over the step's {len(theta)} jittered "
+                  f"draws, {dt:.1f} s), oracle/liboracle.so (g++ -O3 -DNDEBUG, no -march=native, no FMA), "
+                  f"OpenMP over chains on {cores} threads; single thread: {n1 / dt1:.1f} evals/s",
         "single_thread_value": n1 / dt1,
     }
 
@@ -152,6 +159,21 @@ def main():
     acc = d_acc.cpu().numpy().astype(np.float64)
     rej = d_rej.cpu().numpy().astype(np.float64)
 
+    # the other arithmetic mode, same draws, reported next to the headline (not part of `value`)
+    other = "strict" if args.arith == "fma" else "fma"
+    hip.set_arith(mm.ARITH_STRICT if other == "strict" else mm.ARITH_FMA)
+    step(0)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    n_other = max(1, min(K, 5))
+    for i in range(n_other):
+        step(i)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    other_ms = e0.elapsed_time(e1) / n_other
+    hip.set_arith(pb.arith)
+
     allgather_ms = None
     if args.allgather and world > 1:
         # post-calibration ensemble summary record per chain: [P means | P variances |
@@ -196,7 +218,9 @@ def main():
                 "workload": f"BASELINE configs[1]: SEPAIHRD {pb.n} age groups, {args.solver}, "
                             f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
                 "chains_per_gpu": B, "n_params": P, "abs_err": pb.abs_err, "rel_err": pb.rel_err,
-                "arith": args.arith, "draws": "reflect(base + sigma*N(0,1)), mt19937(1+chain), libstdc++ order",
+                "arith": args.arith, "other_arith": {"mode": other, "kernel_ms": other_ms,
+                                                     "evals_per_s_per_gpu": B / (other_ms * 1e-3)},
+                "draws": "reflect(base + sigma*N(0,1)), mt19937(1+chain), libstdc++ order",
                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
             },
             "roofline": {

@@ -229,12 +229,35 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
     const int num_obs_points = T - runup_offset;
     const int n_obs = pb->n_obs;
     const double qnan = std::numeric_limits<double>::quiet_NaN();
-    std::vector<double> obs((size_t)3 * std::max(n_obs, 1) * lpc, qnan);
+    // grid records: [T][lpc][4] = {obs_H, obs_ICU, obs_D, times[k+1]}
+    std::vector<double> grid((size_t)T * lpc * 4, qnan);
     const double* obs_ptr[3] = {pb->obs_H, pb->obs_ICU, pb->obs_D};
-    for (int s = 0; s < 3; ++s)
-        for (int r = 0; r < n_obs; ++r)
-            for (int i = 0; i < n; ++i)
-                obs[((size_t)s * n_obs + r) * lpc + i] = obs_ptr[s][(size_t)r * n + i];
+    for (int k = 0; k < T; ++k)
+        for (int i = 0; i < lpc; ++i) {
+            double* rec = &grid[((size_t)k * lpc + i) * 4];
+            const int r = k - runup_offset;
+            if (i < n && r >= 0 && r < n_obs)
+                for (int s = 0; s < 3; ++s) rec[s] = obs_ptr[s][(size_t)r * n + i];
+            rec[3] = pb->times[k + 1 < T ? k + 1 : T - 1];
+        }
+
+    // merged beta/kappa schedule (see DevProblem)
+    std::vector<double> mends;
+    for (int k = 0; k < nb; ++k) mends.push_back(pb->beta_end_times[k]);
+    for (int k = 0; k < nk; ++k) mends.push_back(pb->kappa_end_times[k]);
+    std::sort(mends.begin(), mends.end());
+    mends.erase(std::unique(mends.begin(), mends.end()), mends.end());
+    const int nm = (int)mends.size();
+    std::vector<int32_t> seg_ib(nm + 1, 0), seg_ik(nm + 1, 0);
+    for (int j = 0; j <= nm; ++j) {
+        const double trep = j < nm ? mends[j] : std::numeric_limits<double>::infinity();
+        int cb = 0, ckk = 0;
+        for (int k = 0; k < nb; ++k) cb += (trep > pb->beta_end_times[k]) ? 1 : 0;
+        for (int k = 0; k < nk; ++k) ckk += (trep > pb->kappa_end_times[k]) ? 1 : 0;
+        seg_ib[j] = nb > 0 ? std::min(cb, nb - 1) : 0;
+        seg_ik[j] = std::min(ckk, nk - 1);
+    }
+    if (nm & 1) mends.push_back(std::numeric_limits<double>::infinity());
 
     double max_gap = 0.0;
     for (int i = 1; i < T; ++i) max_gap = std::max(max_gap, pb->times[i] - pb->times[i - 1]);
@@ -259,7 +282,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
 
     bool ok = true;
     d.times = upload(ctx, std::vector<double>(pb->times, pb->times + T), ok);
-    d.obs = upload(ctx, obs, ok);
+    d.grid = upload(ctx, grid, ok);
     d.lower = upload(ctx, ctx->lower, ok);
     d.upper = upload(ctx, ctx->upper, ok);
     d.has_bounds = upload(ctx, hb, ok);
@@ -273,6 +296,10 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
     d.init_state = upload(ctx, init, ok);
     d.beta_ends = upload(ctx, std::vector<double>(pb->beta_end_times, pb->beta_end_times + nb), ok);
     d.kappa_ends = upload(ctx, std::vector<double>(pb->kappa_end_times, pb->kappa_end_times + nk), ok);
+    d.nm = nm; d.nm_pad = (int)mends.size();
+    d.mends = upload(ctx, mends, ok);
+    d.seg_ib = upload(ctx, seg_ib, ok);
+    d.seg_ik = upload(ctx, seg_ik, ok);
     if (!ok) {
         set_err(err, errlen, "device allocation / upload failed");
         sepaihrd_destroy(ctx);

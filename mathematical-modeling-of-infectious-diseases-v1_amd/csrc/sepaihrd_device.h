@@ -27,7 +27,10 @@ struct DevProblem {
     int32_t constraint_mode, kappa_calibrated, max_attempts, obs_rows_match;
     double abs_tol, rel_tol, dt_hint, max_gap;
     const double* times;         // [T]
-    const double* obs;           // [3][n_obs][lpc]  (H, ICU, D)
+    // per output point k and lane (age): {obs_H, obs_ICU, obs_D, times[k+1]} -- 32 bytes, fetched by
+    // two 16-byte LDS-DMA loads one RK step ahead of use.  NaN observations for k < runup_offset
+    // and for padded ages; times[T] := times[T-1].
+    const double* grid;          // [T][lpc][4]
     const double* lower;         // [P]
     const double* upper;         // [P]
     const int32_t* has_bounds;   // [P]
@@ -41,6 +44,12 @@ struct DevProblem {
     const double* init_state;    // [11][lpc]
     const double* beta_ends;     // [nb]
     const double* kappa_ends;    // [nk]
+    // merged schedule: union of the beta and kappa end times, sorted; segment j = (mends[j-1], mends[j]],
+    // segment nm = (mends[nm-1], +inf).  seg_ib / seg_ik: value index of each schedule on segment j.
+    int32_t nm, nm_pad;          // nm_pad = nm rounded up to even (padded with +inf)
+    const double* mends;         // [nm_pad]
+    const int32_t* seg_ib;       // [nm + 1]
+    const int32_t* seg_ik;       // [nm + 1]
 };
 
 struct EvalOutputs {
@@ -70,9 +79,15 @@ inline int lanes_per_chain(int n) {
     while (l < n) l <<= 1;
     return l;
 }
+// LDS carve (one wavefront per block), in doubles:
+//   [0, 256)                      grid-record landing zone: 2 x (64 lanes x 16 B), LDS-DMA destination
+//   [256, 256 + nm_pad)           merged period end times (+inf padded to an even count)
+//   [.., + cpw*(nm+1))            per-chain beta*kappa of every merged segment
+//   [.., + cpw*P)                 constrained theta of the wave's chains (prologue only)
+constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;
 inline size_t eval_lds_bytes(const DevProblem& pb) {
     const int cpw = WAVE / pb.lpc;
-    return (size_t)cpw * (pb.P + pb.nb + pb.nk) * sizeof(double);
+    return ((size_t)LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P) * sizeof(double);
 }
 
 }  // namespace sepaihrd

@@ -154,11 +154,12 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     const double S = x[0], E = x[1], P = x[2], A = x[3], I = x[4], H = x[5], ICU = x[6];
     const double total_inf = P + A + q.theta * I;
     const double inf_pressure = total_inf * q.h_infec * q.inv_N;
-    double lambda = 0.0;
-    // lambda_i += M(i,j) * pi_j, j ascending (column-major walk of the reference)
+    // lambda_i = 0.0 + M(i,0) pi_0 + M(i,1) pi_1 + ..., j ascending (column-major walk of the reference).
+    // The leading "0.0 +" only turns a -0.0 first product into +0.0, which max(0.0, .) below does anyway.
+    double lambda = q.Mrow[0] * group_bcast<LPC, 0>(inf_pressure);
     [&]<int... J>(std::integer_sequence<int, J...>) {
-        ((lambda += q.Mrow[J] * group_bcast<LPC, J>(inf_pressure)), ...);
-    }(std::make_integer_sequence<int, LPC>{});
+        ((lambda += q.Mrow[J + 1] * group_bcast<LPC, J + 1>(inf_pressure)), ...);
+    }(std::make_integer_sequence<int, LPC - 1>{});
     lambda *= beta_eff * q.a;
     const double lambda_val = (0.0 < lambda) ? lambda : 0.0;  // std::max(0.0, lambda)
 
@@ -210,45 +211,98 @@ __device__ __forceinline__ double constrain(double v, double lo, double hi, int 
     return fabs(v);
 }
 
-// piecewise-constant lookup: value index = #(ends < t), clamped to the last period
-__device__ __forceinline__ int period_index(const double* __restrict__ ends, int count, double t) {
-    int idx = 0;
-    for (int k = 0; k < count; ++k) idx += (t > ends[k]) ? 1 : 0;
-    return idx < count - 1 ? idx : count - 1;
-}
-
+// Merged beta*kappa schedule of one chain.  Segment j = (mends[j-1], mends[j]], value index = #(mends < t).
 struct Schedule {
-    const double* sb;  // LDS: this chain's beta values  [nb]
-    const double* sk;  // LDS: this chain's kappa values [nk]
-    double beta_const; // used when nb == 0
-    // cached segment (lo, hi] on which beta*kappa is constant
-    double lo, hi, bk;
+    const double* me;   // LDS: merged end times, +inf padded to an even count (block-uniform)
+    const double* bkv;  // LDS: this chain's beta*kappa per merged segment [nm + 1]
+    double lo, hi, bk;  // cached segment (lo, hi] and its value
 };
 
-__device__ __forceinline__ double beta_kappa_at(const DevProblem& pb, const Schedule& s, double t) {
-    const double beta = (pb.nb > 0) ? s.sb[period_index(pb.beta_ends, pb.nb, t)] : s.beta_const;
-    const double kappa = s.sk[period_index(pb.kappa_ends, pb.nk, t)];
-    return beta * kappa;
-}
-
-__device__ __forceinline__ void refresh_segment(const DevProblem& pb, Schedule& s, double t) {
-    double lo = -INFINITY, hi = INFINITY;
-    double beta = s.beta_const;
-    if (pb.nb > 0) {
-        const int ib = period_index(pb.beta_ends, pb.nb, t);
-        beta = s.sb[ib];
-        if (ib > 0) lo = pb.beta_ends[ib - 1];
-        if (ib < pb.nb - 1) hi = pb.beta_ends[ib];
+// segment indices of two times in one pass over the merged end times (uniform LDS broadcast reads)
+__device__ __forceinline__ void segment_index2(const Schedule& s, int nm_pad, double ta, double tb, int& ca,
+                                               int& cb) {
+    ca = 0; cb = 0;
+    for (int j = 0; j < nm_pad; j += 2) {
+        const double2 e = *reinterpret_cast<const double2*>(s.me + j);
+        ca += (ta > e.x) ? 1 : 0; ca += (ta > e.y) ? 1 : 0;
+        cb += (tb > e.x) ? 1 : 0; cb += (tb > e.y) ? 1 : 0;
     }
-    const int ik = period_index(pb.kappa_ends, pb.nk, t);
-    if (ik > 0) lo = fmax(lo, pb.kappa_ends[ik - 1]);
-    if (ik < pb.nk - 1) hi = fmin(hi, pb.kappa_ends[ik]);
-    s.lo = lo;
-    s.hi = hi;
-    s.bk = beta * s.sk[ik];
 }
 
 #define SEP_UNROLL _Pragma("unroll")
+
+// Diagnostic build only (-DSEPAIHRD_STAMPS): s_memtime stamps at section boundaries of the RK loop,
+// summed per wave and written to out.ll_parts of the wave's first chain.  Never in the product build.
+#ifdef SEPAIHRD_STAMPS
+#define SEP_STAMP(var)                                                                 \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#else
+#define SEP_STAMP(var) do { } while (0)
+#endif
+
+// ----------------------------------------------------------------------------------
+// natural log for the Poisson term.  Argument reduction x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2),
+// s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the classic degree-14 minimax
+// R (error < 2^-58.45 on the reduced interval); < 1 ulp overall, ~45 instructions instead of the
+// device library's ~125.  Explicit fma() here is not contraction: the likelihood's log is a libm
+// call in the reference (std::log), never bit-pinned.  Non-positive / non-finite / subnormal
+// arguments take the device library path.
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ double log_pos(double x) {
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    const bool regular = (x >= 2.2250738585072014e-308) && (x < INFINITY);
+    if (__ballot(!regular) != 0ull) return log(x);  // wave-uniform: rare
+    int k = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                            // [sqrt(1/2), sqrt(2))
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double dk = (double)k;
+    const double sdiv = f / (2.0 + f);
+    const double z = sdiv * sdiv;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - fma(sdiv, hfsq + R, dk * ln2_lo)) - f);
+}
+
+// exp for the step-size controller: p = k ln2 + r, |r| <= ln2/2, degree-13 Taylor (remainder < 5e-18).
+__device__ __forceinline__ double exp_ctl(double p) {
+    constexpr double log2e = 1.44269504088896338700e+00;
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double kd = rint(p * log2e);
+    double r = fma(-kd, ln2_hi, p);
+    r = fma(-kd, ln2_lo, r);
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)kd);
+}
+// x^c for the controller's err^(-1/3), err^(-1/5): exp(c log x), a few ulp -- the reference calls
+// std::pow (libm, not bit-pinned); the result only scales the next trial step.
+__device__ __forceinline__ double pow_ctl(double x, double c) { return exp_ctl(c * log_pos(x)); }
 
 // ----------------------------------------------------------------------------------
 // the evaluation kernel: block = one wavefront = 64/LPC chains
@@ -258,7 +312,11 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
                                                               const double* __restrict__ theta,
                                                               const int B, const EvalOutputs out) {
     constexpr int CPW = WAVE / LPC;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const lds_rec = lds;                       // [2][64 lanes][2]  LDS-DMA landing zone
+    double* const lds_mends = lds + LDS_REC_DOUBLES;   // [nm_pad]
+    double* const lds_bk = lds_mends + pb.nm_pad;      // [CPW][nm + 1]
+    double* const lds_theta = lds_bk + CPW * (pb.nm + 1);
     const int lane = threadIdx.x;
     const int grp = lane / LPC;
     const int age = lane % LPC;
@@ -278,12 +336,12 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         const double* src = theta + chain0 * P;
         for (int idx = lane; idx < total; idx += WAVE) {
             const int p = idx % P;
-            lds[idx] = constrain(src[idx], pb.lower[p], pb.upper[p], pb.has_bounds[p], pb.constraint_mode);
+            lds_theta[idx] = constrain(src[idx], pb.lower[p], pb.upper[p], pb.has_bounds[p], pb.constraint_mode);
         }
     }
+    for (int k = lane; k < pb.nm_pad; k += WAVE) lds_mends[k] = pb.mends[k];
     __syncthreads();
-    const double* th = lds + g * P;
-    double* sched = lds + CPW * P + grp * (pb.nb + pb.nk);  // own region even for shadow groups
+    const double* th = lds_theta + g * P;
 
     auto scalar_slot = [&](int slot) -> double {
         const int s = pb.src_scalar[slot];
@@ -316,17 +374,24 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
     SEP_UNROLL
     for (int j = 0; j < LPC; ++j) q.Mrow[j] = pb.Mrow[age * LPC + j];
 
+    // beta(t) kappa(t) on every merged segment: "current_beta * reduction_factor" of the RHS, once per chain
     Schedule sch;
-    sch.sb = sched;
-    sch.sk = sched + pb.nb;
-    sch.beta_const = scalar_slot(SS_BETA);
-    for (int k = age; k < pb.nb + pb.nk; k += LPC) sched[k] = scalar_slot(SS_SCHEDULE0 + k);
+    sch.me = lds_mends;
+    {
+        double* bkv = lds_bk + grp * (pb.nm + 1);  // own region even for shadow groups
+        for (int j = age; j <= pb.nm; j += LPC) {
+            const double beta = (pb.nb > 0) ? scalar_slot(SS_SCHEDULE0 + pb.seg_ib[j]) : scalar_slot(SS_BETA);
+            const double kappa = scalar_slot(SS_SCHEDULE0 + pb.nb + pb.seg_ik[j]);
+            bkv[j] = beta * kappa;
+        }
+        sch.bkv = bkv;
+    }
     __syncthreads();
 
     int status = 0;
     if (pb.kappa_calibrated) {  // setCalibratableValues: any after-baseline kappa < 0 -> throw -> lowest()
         bool neg = false;
-        for (int k = 1; k < pb.nk; ++k) neg |= (sch.sk[k] < 0.0);
+        for (int k = 1; k < pb.nk; ++k) neg |= (scalar_slot(SS_SCHEDULE0 + pb.nb + k) < 0.0);
         if (neg) status = 1;
     }
     if (!pb.obs_rows_match) status = 1;  // SEPAIHRDObjectiveFunction.cpp:176-178
@@ -360,33 +425,45 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
     const int T = pb.T;
     const int n_real = pb.n;
 
-    auto observe = [&](int k) {
+    // grid record of output index k for this lane: {obs_H, obs_ICU, obs_D, times[k+1]}.
+    // request_record() is an LDS-DMA (global_load_lds_dwordx4 x2): no VGPR destination, nothing to
+    // wait for until the record is read one whole RK step later.
+    const double* grid_lane = pb.grid + (size_t)age * 4;
+    auto request_record = [&](int k) {
+        const double* src = grid_lane + (size_t)k * (LPC * 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)lds_rec, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2),
+                                         (__attribute__((address_space(3))) void*)(lds_rec + 2 * WAVE), 16, 0, 0);
+    };
+    auto read_record = [&](double& oH, double& oI, double& oD, double& tn) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double2 a = *reinterpret_cast<const double2*>(lds_rec + 2 * lane);
+        const double2 b = *reinterpret_cast<const double2*>(lds_rec + 2 * WAVE + 2 * lane);
+        oH = a.x; oI = a.y; oD = b.x; tn = b.y;
+    };
+
+    auto observe = [&](int k, double oH, double oI, double oD) {
         double incH = x[9] - prevH, incICU = x[10] - prevICU, incD = x[8] - prevD;
         incH = (incH < 0.0) ? 0.0 : incH;  // cwiseMax(0.0)
         incICU = (incICU < 0.0) ? 0.0 : incICU;
         incD = (incD < 0.0) ? 0.0 : incD;
         prevH = x[9]; prevICU = x[10]; prevD = x[8];
         if (k >= pb.runup_offset) {
-            const int row = k - pb.runup_offset;
-            const double* o = pb.obs + (size_t)row * LPC + age;
-            const size_t stream_stride = (size_t)pb.n_obs * LPC;
-            const double oH = o[0], oI = o[stream_stride], oD = o[2 * stream_stride];
             const double eps = 1e-10;
             auto term = [&](double obs, double sim) -> double {
-                if (obs >= 0.0 && isfinite(obs)) {
-                    if (sim < 0.0) sim = 0.0;
-                    sim += eps;
-                    return obs * log(sim) - sim;
-                }
-                return 0.0;
+                if (sim < 0.0) sim = 0.0;
+                sim += eps;
+                const double v = obs * log_pos(sim) - sim;
+                return (obs >= 0.0 && isfinite(obs)) ? v : 0.0;
             };
             const double tH = term(oH, incH), tI = term(oI, incICU), tD = term(oD, incD);
             // row_sum over ages in ascending order (serial order of calculateSingleLogLikelihood)
             auto row_sum = [&](double tv) -> double {
-                double rs = 0.0;
+                double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
                 [&]<int... J>(std::integer_sequence<int, J...>) {
-                    ((rs += group_bcast<LPC, J>(tv)), ...);
-                }(std::make_integer_sequence<int, LPC>{});
+                    ((rs += group_bcast<LPC, J + 1>(tv)), ...);
+                }(std::make_integer_sequence<int, LPC - 1>{});
                 return rs;
             };
             llH += row_sum(tH);
@@ -401,26 +478,40 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
     };
 
     // ---- 4. integrate_times(controlled stepper, ..., times, dt_hint, observer)
-    bool active = (status == 0) && (T > 0);
+    bool active = (status == 0);
     int k_next = 1;  // index of the next output time to reach
-    double t = (T > 0) ? pb.times[0] : 0.0;
-    double t_next = (T > 1) ? pb.times[1] : t;
+    double t = pb.times[0];
+    double t_next;
     double dt = pb.dt_hint;
     int fails = 0;
     int attempts = 0;
-    if (active) observe(0);
+    {
+        const double* r0 = grid_lane;  // record 0 is read directly
+        const double oH = r0[0], oI = r0[1], oD = r0[2];
+        t_next = r0[3];
+        if (active) observe(0, oH, oI, oD);
+    }
     if (T <= 1) active = false;
+    // software prefetch: the record of the next output (its observations and the time after it) is
+    // requested one whole RK step before it is needed, so no step waits on HBM/L2 latency
+    if (active) request_record(1);
 
     sch.lo = INFINITY; sch.hi = -INFINITY; sch.bk = 0.0;  // empty segment: first step refreshes
     double k1[NUM_COMP];
     if (SOLVER == 0) {  // controlled FSAL stepper: initialize() at the first try_step
-        const double bk0 = beta_kappa_at(pb, sch, t);
-        rhs<LPC>(q, x, k1, bk0);
+        int c0, c1;
+        segment_index2(sch, pb.nm_pad, t, t, c0, c1);
+        rhs<LPC>(q, x, k1, sch.bkv[c0]);
     }
 
     const double eps_abs = pb.abs_tol, eps_rel = pb.rel_tol;
 
+#ifdef SEPAIHRD_STAMPS
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    unsigned long long acc_head = 0, acc_body = 0, acc_err = 0, acc_tail = 0;
+#endif
     while (__ballot(active) != 0ull) {
+        SEP_STAMP(st0);
         // min_abs(dt, t_next - t); finished chains idle with a harmless unit step
         const double cur = active ? fmin(dt, t_next - t) : 1.0;
 
@@ -440,15 +531,32 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
             const double tmax = (SOLVER == 0) ? tau[6] : tau[4];
             const bool in_seg = (tmin > sch.lo) && (tmax <= sch.hi);
             if (__ballot(active && !in_seg) != 0ull) {
-                SEP_UNROLL
-                for (int s = 0; s < 7; ++s) bks[s] = beta_kappa_at(pb, sch, tau[s]);
-                refresh_segment(pb, sch, tau[6]);
+                // some chain's step leaves its cached segment: look the stages up again (rare)
+                int c_lo, c_hi;
+                segment_index2(sch, pb.nm_pad, tmin, tmax, c_lo, c_hi);
+                const double v_lo = sch.bkv[c_lo], v_hi = sch.bkv[c_hi];
+                if (__ballot(c_hi > c_lo + 1) == 0ull) {
+                    // at most one breakpoint b inside the step: stages <= b take v_lo, later ones v_hi
+                    const double bpt = (c_lo < pb.nm) ? sch.me[c_lo] : INFINITY;
+                    SEP_UNROLL
+                    for (int s = 0; s < 7; ++s) bks[s] = (tau[s] > bpt) ? v_hi : v_lo;
+                } else {
+                    for (int s = 0; s < 7; ++s) {
+                        int ca, cb;
+                        segment_index2(sch, pb.nm_pad, tau[s], tau[s], ca, cb);
+                        bks[s] = sch.bkv[ca];
+                    }
+                }
+                sch.lo = (c_hi > 0) ? sch.me[c_hi - 1] : -INFINITY;
+                sch.hi = (c_hi < pb.nm) ? sch.me[c_hi] : INFINITY;
+                sch.bk = v_hi;
             } else {
                 SEP_UNROLL
                 for (int s = 0; s < 7; ++s) bks[s] = sch.bk;
             }
         }
 
+        SEP_STAMP(st1);
         double k2[NUM_COMP], k3[NUM_COMP], k4[NUM_COMP], k5[NUM_COMP], k6[NUM_COMP];
         double xt[NUM_COMP], xnew[NUM_COMP], xerr[NUM_COMP];
         double k7[NUM_COMP];
@@ -513,14 +621,26 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
                   xerr[c] = e1 * k1[c] + e3 * k3[c] + e4 * k4[c] + e5 * k5[c] + e6 * k6[c]; }
         }
 
-        // default_error_checker: max_i |xerr_i| / (eps_abs + eps_rel (|x_i| + dt |dxdt_i|)), start-of-step x, dxdt
-        double err = 0.0;
+        // default_error_checker: err = max_i |xerr_i| / (eps_abs + eps_rel (|x_i| + dt |dxdt_i|)) with the
+        // start-of-step x, dxdt; reject iff err > 1.  |e| <= s  =>  fl(|e|/s) <= 1 exactly (division is
+        // monotone), so the 11 divisions are only needed when some quotient may exceed 1 or when the
+        // value of err feeds the step-size controller (dt below the largest output gap).
+        SEP_STAMP(st2);
+        double sc[NUM_COMP], ea[NUM_COMP];
+        bool over = false;
         SEP_UNROLL
         for (int c = 0; c < NUM_COMP; ++c) {
-            const double e = fabs(xerr[c]) / (eps_abs + eps_rel * (fabs(x[c]) + cur * fabs(k1[c])));
-            err = max_keep(err, e);
+            sc[c] = eps_abs + eps_rel * (fabs(x[c]) + cur * fabs(k1[c]));
+            ea[c] = fabs(xerr[c]);
+            over |= (ea[c] > sc[c]);
         }
-        err = group_max<LPC>(err);
+        const bool need_err = active && (over || (dt < pb.max_gap));
+        double err = 0.0;
+        if (__ballot(need_err) != 0ull) {
+            SEP_UNROLL
+            for (int c = 0; c < NUM_COMP; ++c) err = max_keep(err, ea[c] / sc[c]);
+            err = group_max<LPC>(err);
+        }
 
         const bool reject = err > 1.0;
         ++attempts;
@@ -530,15 +650,16 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         const bool need_inc = active && !reject && (err < 0.5) && (dt < pb.max_gap);
         double cur_after = cur;
         if (__ballot(need_dec) != 0ull) {
-            const double f = fmax(9.0 / 10.0 * pow(err, -1.0 / (4 - 1)), 1.0 / 5.0);
+            const double f = fmax(9.0 / 10.0 * pow_ctl(err, -1.0 / (4 - 1)), 1.0 / 5.0);
             if (need_dec) cur_after = cur * f;
         }
         if (__ballot(need_inc) != 0ull) {
-            const double e2 = fmax(pow(5.0, -5.0), err);
-            const double f = 9.0 / 10.0 * pow(e2, -1.0 / 5);
+            const double e2 = fmax(1.0 / 3125.0, err);  // std::pow(5.0, -5.0) == 1/3125 exactly rounded
+            const double f = 9.0 / 10.0 * pow_ctl(e2, -1.0 / 5);
             if (need_inc) cur_after = cur * f;
         }
 
+        SEP_STAMP(st3);
         if (active) {
             if (reject) {
                 ++n_rej;
@@ -558,14 +679,21 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
                 // less_with_sign(t, t_next, dt): t_next - t > epsilon
                 if (!((t_next - t) > DBL_EPSILON)) {
                     t = t_next;  // integrate_times re-reads the exact grid time
-                    observe(k_next);
+                    double oH, oI, oD, tn;
+                    read_record(oH, oI, oD, tn);
+                    observe(k_next, oH, oI, oD);
                     ++k_next;
+                    t_next = tn;
                     if (k_next >= T) active = false;
-                    else t_next = pb.times[k_next];
+                    else request_record(k_next);
                 }
             }
             if (active && attempts >= pb.max_attempts) { status = 3; active = false; }
         }
+        SEP_STAMP(st4);
+#ifdef SEPAIHRD_STAMPS
+        acc_head += st1 - st0; acc_body += st2 - st1; acc_err += st3 - st2; acc_tail += st4 - st3;
+#endif
     }
 
     // ---- 5. total (SEPAIHRDObjectiveFunction.cpp:222-227)
@@ -581,7 +709,20 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
             out.ll_parts[3 * chain + 0] = llH;
             out.ll_parts[3 * chain + 1] = llICU;
             out.ll_parts[3 * chain + 2] = llD;
+#ifdef SEPAIHRD_STAMPS
+            if (grp == 0) {  // cycles: head / RK body / error+controller ; tail goes to chain0+1
+                out.ll_parts[3 * chain + 0] = (double)acc_head;
+                out.ll_parts[3 * chain + 1] = (double)acc_body;
+                out.ll_parts[3 * chain + 2] = (double)acc_err;
+            }
+#endif
         }
+#ifdef SEPAIHRD_STAMPS
+        if (out.ll_parts && grp == 1) {
+            out.ll_parts[3 * chain + 0] = (double)acc_tail;
+            out.ll_parts[3 * chain + 1] = (double)attempts;
+        }
+#endif
     }
 }
 

@@ -1,0 +1,26 @@
+"""Runs the diagnostic stamps build (tools/libsepaihrd_stamps.so) and prints where a wave's cycles go.
+Diagnostic only: its run time is not a benchmark number."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mmid_amd_loader
+mm = mmid_amd_loader.load()
+from mmid_amd import draws, hipabi
+arith = sys.argv[1] if len(sys.argv) > 1 else "strict"
+hipabi._lib = hipabi.load_library(os.path.join(ROOT, "tools", "libsepaihrd_stamps.so"))
+pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", "synth_400d_n4.json"))
+pb.arith = mm.ARITH_FMA if arith == "fma" else mm.ARITH_STRICT
+theta = draws.jitter_draws(pb, 1, 4096)
+hip = mm.HipObjective(pb)
+hip.eval_batch(theta)
+r = hip.eval_batch(theta)
+parts = r["ll_parts"].reshape(-1, 16, 3)  # per wave: 16 chains
+head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
+tail, att = parts[:, 1, 0], parts[:, 1, 1]
+tot = head + body + err + tail
+print("arith", arith, "waves", len(tot), "attempts/wave mean %.1f" % att.mean())
+for name, v in (("head(stage times, schedule)", head), ("RK body (6 RHS + stage sums + xerr)", body),
+                ("error norm + controller", err), ("accept/observe/likelihood tail", tail)):
+    print("%-40s %8.0f cycles/attempt  %5.1f %%" % (name, (v / att).mean(), 100 * v.sum() / tot.sum()))
+print("total stamped cycles/attempt %.0f (s_memtime ticks)" % (tot / att).mean())
