@@ -115,7 +115,7 @@ def build_problem_struct(pb: SEPAIHRDProblem, keep: list) -> sepaihrd_problem:
     s.n_age, s.n_times, s.n_obs = n, pb.n_times, pb.n_obs
     s.n_beta, s.n_kappa, s.n_params = len(pb.beta_values), len(pb.kappa_values), pb.n_params
     s.solver, s.constraint_mode, s.arith = pb.solver, pb.constraint_mode, pb.arith
-    s.max_attempts = 0
+    s.max_attempts = int(getattr(pb, "max_attempts", 0))
 
     def dbl(x):
         a = np.ascontiguousarray(x, dtype=np.float64)

@@ -1,0 +1,176 @@
+// HipSEPAIHRD.hpp -- host-side (C++) mirror of the reference's plug-in surface for the MCMC
+// likelihood path, backed by the C ABI of include/sepaihrd_hip.h.
+//
+//   HipSEPAIHRDParameterManager   <- SEPAIHRDParameterManager
+//                                    (include/model/parameters/SEPAIHRDParameterManager.hpp,
+//                                     src/model/parameters/SEPAIHRDParameterManager.cpp)
+//   HipSEPAIHRDObjectiveFunction  <- SEPAIHRDObjectiveFunction
+//                                    (include/model/objectives/SEPAIHRDObjectiveFunction.hpp:49-58,
+//                                     src/model/objectives/SEPAIHRDObjectiveFunction.cpp)
+//   SimulationCache               <- src/sir_age_structured/caching/SimulationCache.cpp
+//   MultiChainMetropolisHastings  <- MetropolisHastingsSampler
+//                                    (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp)
+//                                    run for C independent chains in lock-step so that every
+//                                    iteration is ONE batched device evaluation.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <random>
+#include <unordered_map>
+
+#include "Interfaces.hpp"
+
+struct sepaihrd_ctx;
+
+namespace epidemic {
+
+// include/model/parameters/SEPAIHRDParameters.hpp:20-124 (fields used on this path)
+struct SEPAIHRDParameters {
+    Eigen::VectorXd N;
+    Eigen::MatrixXd M_baseline;
+    double beta = 0.0;
+    std::vector<double> beta_end_times, beta_values;
+    Eigen::VectorXd a, h_infec;
+    double theta = 0, sigma = 0, gamma_p = 0, gamma_A = 0, gamma_I = 0, gamma_H = 0, gamma_ICU = 0;
+    Eigen::VectorXd p, h, icu, d_H, d_ICU, d_community;
+    std::vector<double> kappa_end_times, kappa_values;  // baseline period first
+    double E0_multiplier = 1, P0_multiplier = 1, A0_multiplier = 1, I0_multiplier = 1, H0_multiplier = 1,
+           ICU0_multiplier = 1, R0_multiplier = 1, D0_multiplier = 1;
+    double runup_days = 30.0, seed_exposed = 10.0;
+};
+
+// include/model/parameters/SEPAIHRDParameterManager.hpp:22-25
+enum class ConstraintMode { OPTIMIZATION_CLAMP = 0, MCMC_REFLECT = 1 };
+
+// observed matrices as SEPAIHRDObjectiveFunction reads them from CalibrationData (T_obs x n)
+class CalibrationData {
+public:
+    CalibrationData(const Eigen::MatrixXd& new_hospitalizations, const Eigen::MatrixXd& new_icu,
+                    const Eigen::MatrixXd& new_deaths, const Eigen::VectorXd& population)
+        : hosp_(new_hospitalizations), icu_(new_icu), deaths_(new_deaths), pop_(population) {}
+    const Eigen::MatrixXd& getNewHospitalizations() const { return hosp_; }
+    const Eigen::MatrixXd& getNewICU() const { return icu_; }
+    const Eigen::MatrixXd& getNewDeaths() const { return deaths_; }
+    const Eigen::VectorXd& getPopulationByAgeGroup() const { return pop_; }
+private:
+    Eigen::MatrixXd hosp_, icu_, deaths_;
+    Eigen::VectorXd pop_;
+};
+
+class SimulationCache : public ISimulationCache {
+public:
+    explicit SimulationCache(size_t max_size = 1000);
+    size_t computeHash(const Eigen::VectorXd& params) const;  // theta quantised to 1e-8
+    bool getLikelihood(size_t key, double& value);
+    void storeLikelihood(size_t key, double value);
+    std::optional<double> get(const Eigen::VectorXd& parameters) override;
+    void set(const Eigen::VectorXd& parameters, double result) override;
+    void clear() override;
+    size_t size() const override;
+    std::string createCacheKey(const Eigen::VectorXd& parameters) const override;
+    bool getLikelihood(const std::string& key, double& value) override;
+    void storeLikelihood(const std::string& key, double value) override;
+    size_t getLikelihoodCalls() const { return calls_; }
+    size_t getLikelihoodHits() const { return hits_; }
+private:
+    struct Entry { double value; uint64_t freq, tick; };
+    size_t capacity_;
+    uint64_t tick_ = 0;
+    size_t calls_ = 0, hits_ = 0;
+    std::unordered_map<size_t, Entry> map_;
+};
+
+class HipSEPAIHRDParameterManager : public IParameterManager {
+public:
+    // npi_param_names: names of kappa_values[1..] (PiecewiseConstantNpiStrategy's calibratable names;
+    // empty -> "kappa_2", "kappa_3", ...)
+    HipSEPAIHRDParameterManager(const SEPAIHRDParameters& model_params,
+                                const std::vector<std::string>& params_to_calibrate,
+                                const std::map<std::string, double>& proposal_sigmas,
+                                const std::map<std::string, std::pair<double, double>>& param_bounds,
+                                const std::vector<std::string>& npi_param_names = {});
+    Eigen::VectorXd getCurrentParameters() const override;
+    void updateModelParameters(const Eigen::VectorXd& parameters) override;
+    const std::vector<std::string>& getParameterNames() const override { return names_; }
+    size_t getParameterCount() const override { return names_.size(); }
+    double getSigmaForParamIndex(int index) const override;
+    Eigen::VectorXd applyConstraints(const Eigen::VectorXd& parameters) const override;
+    int getIndexForParam(const std::string& name) const override;
+    double getLowerBoundForParamIndex(int idx) const override;
+    double getUpperBoundForParamIndex(int idx) const override;
+    void setConstraintMode(ConstraintMode m) { mode_ = m; }
+    ConstraintMode getConstraintMode() const { return mode_; }
+    // resolved theta -> field map (enum sepaihrd_field / index), done once
+    const std::vector<int32_t>& fieldCodes() const { return field_; }
+    const std::vector<int32_t>& fieldIndices() const { return index_; }
+    const SEPAIHRDParameters& modelParameters() const { return params_; }
+    bool hasBounds(int idx) const { return has_bounds_[static_cast<size_t>(idx)] != 0; }
+private:
+    double* slot(int field, int index);
+    SEPAIHRDParameters params_;
+    std::vector<std::string> names_, npi_names_;
+    std::vector<double> sigma_, lower_, upper_;
+    std::vector<uint8_t> has_bounds_;
+    std::vector<int32_t> field_, index_;
+    ConstraintMode mode_ = ConstraintMode::OPTIMIZATION_CLAMP;
+};
+
+class HipSEPAIHRDObjectiveFunction : public virtual IObjectiveFunction, public IBatchObjectiveFunction {
+public:
+    // Same argument order and meaning as SEPAIHRDObjectiveFunction's constructor; the model object is
+    // the parameter manager's SEPAIHRDParameters (the device needs no host model instance).
+    HipSEPAIHRDObjectiveFunction(HipSEPAIHRDParameterManager& parameterManager, ISimulationCache& cache,
+                                 const CalibrationData& calibration_data,
+                                 const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+                                 std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error = 1.0e-6,
+                                 double rel_error = 1.0e-6, int device = -1, bool fma_arithmetic = false);
+    ~HipSEPAIHRDObjectiveFunction() override;
+    HipSEPAIHRDObjectiveFunction(const HipSEPAIHRDObjectiveFunction&) = delete;
+    HipSEPAIHRDObjectiveFunction& operator=(const HipSEPAIHRDObjectiveFunction&) = delete;
+
+    double calculate(const Eigen::VectorXd& parameters) const override;
+    const std::vector<std::string>& getParameterNames() const override;
+    void calculateBatch(const double* thetas, int B, double* out, int* status = nullptr) const override;
+    // per-chain step counters of the last calculateBatch (diagnostics)
+    const std::vector<int32_t>& lastAccepted() const { return n_acc_; }
+    const std::vector<int32_t>& lastRejected() const { return n_rej_; }
+private:
+    void syncConstraintMode() const;
+    HipSEPAIHRDParameterManager& pm_;
+    ISimulationCache& cache_;
+    sepaihrd_ctx* ctx_ = nullptr;
+    mutable int device_mode_ = -1;
+    mutable std::vector<int32_t> n_acc_, n_rej_, status_;
+};
+
+// MetropolisHastingsSampler for many independent chains.  configure() takes the reference's
+// settings keys (mcmc_iterations, burn_in, adaptation_period, thinning, regularization_epsilon,
+// target_acceptance_rate, adapt_scale, store_samples).  A seed replaces the reference's
+// std::random_device (build-side addition): chain c draws from std::mt19937(seed + c) with the
+// reference's draw order (fresh normal_distribution per proposal, uniform only when log_ratio < 0).
+class MultiChainMetropolisHastings : public IOptimizationAlgorithm {
+public:
+    void configure(const std::map<std::string, double>& settings) override;
+    void setSeed(uint32_t seed) { seed_ = seed; }
+    // one chain through the scalar interface (drop-in for MetropolisHastingsSampler)
+    OptimizationResult optimize(const Eigen::VectorXd& initialParameters, IObjectiveFunction& objectiveFunction,
+                                IParameterManager& parameterManager) override;
+    // C chains in lock-step; initial is C x P chain-major
+    std::vector<OptimizationResult> optimizeChains(const std::vector<double>& initial, int C,
+                                                   IBatchObjectiveFunction& objective,
+                                                   IParameterManager& parameterManager);
+    const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
+private:
+    struct Chain;
+    using BatchEval = std::function<void(const double*, int, double*)>;
+    std::vector<OptimizationResult> run(const std::vector<double>& initial, int C, const BatchEval& eval,
+                                        IParameterManager& pm);
+    int iterations_ = 10000, burn_in_ = 1000, adaptation_period_ = 100, thinning_ = 1;
+    double regularization_epsilon_ = 1e-6, target_acceptance_rate_ = 0.234;
+    bool adapt_scale_ = true, store_samples_ = true;
+    uint32_t seed_ = 1;
+    std::vector<std::vector<unsigned char>> traces_;
+};
+
+}  // namespace epidemic

@@ -1,0 +1,202 @@
+// host_capi.cpp -- flat C entry points over the C++ host mirror, for the Python test-suite only.
+// The layout of `sepaihrd_problem` is reused as the carrier of the model / data arrays.
+#include <cstring>
+#include <sstream>
+
+#include "epidemic_hip/HipSEPAIHRD.hpp"
+#include "sepaihrd_hip.h"
+
+using namespace epidemic;
+
+namespace {
+struct HostHandle {
+    std::unique_ptr<HipSEPAIHRDParameterManager> pm;
+    std::unique_ptr<SimulationCache> cache;
+    std::unique_ptr<CalibrationData> data;
+    std::unique_ptr<HipSEPAIHRDObjectiveFunction> obj;
+    std::string error;
+};
+std::vector<std::string> split_lines(const char* s) {
+    std::vector<std::string> out;
+    if (!s) return out;
+    std::stringstream ss(s);
+    std::string line;
+    while (std::getline(ss, line, '\n'))
+        if (!line.empty()) out.push_back(line);
+    return out;
+}
+Eigen::VectorXd vec(const double* p, int n) {
+    Eigen::VectorXd v(n);
+    for (int i = 0; i < n; ++i) v[i] = p ? p[i] : 0.0;
+    return v;
+}
+thread_local std::string g_error;
+}  // namespace
+
+extern "C" {
+
+const char* host_last_error(void) { return g_error.c_str(); }
+
+// names / npi_names: '\n'-joined; sigmas: [P].  Bounds come from pb->lower/upper.
+// with_objective = 0 builds the parameter manager only (no device needed)
+void* host_objective_create(const sepaihrd_problem* pb, const char* names, const char* npi_names,
+                            const double* sigmas, int device, int cache_capacity, int with_objective) {
+    try {
+        const int n = pb->n_age;
+        SEPAIHRDParameters mp;
+        mp.N = vec(pb->N, n);
+        mp.M_baseline = Eigen::MatrixXd(n, n);
+        std::memcpy(mp.M_baseline.data(), pb->M, sizeof(double) * n * n);
+        mp.a = vec(pb->a, n); mp.h_infec = vec(pb->h_infec, n); mp.p = vec(pb->p, n); mp.h = vec(pb->h, n);
+        mp.icu = vec(pb->icu, n); mp.d_H = vec(pb->d_H, n); mp.d_ICU = vec(pb->d_ICU, n);
+        mp.d_community = vec(pb->d_community, n);
+        mp.beta = pb->beta; mp.theta = pb->theta; mp.sigma = pb->sigma; mp.gamma_p = pb->gamma_p;
+        mp.gamma_A = pb->gamma_A; mp.gamma_I = pb->gamma_I; mp.gamma_H = pb->gamma_H; mp.gamma_ICU = pb->gamma_ICU;
+        mp.beta_end_times.assign(pb->beta_end_times, pb->beta_end_times + pb->n_beta);
+        mp.beta_values.assign(pb->beta_values, pb->beta_values + pb->n_beta);
+        mp.kappa_end_times.assign(pb->kappa_end_times, pb->kappa_end_times + pb->n_kappa);
+        mp.kappa_values.assign(pb->kappa_values, pb->kappa_values + pb->n_kappa);
+        mp.E0_multiplier = pb->multipliers[0]; mp.P0_multiplier = pb->multipliers[1];
+        mp.A0_multiplier = pb->multipliers[2]; mp.I0_multiplier = pb->multipliers[3];
+        mp.H0_multiplier = pb->multipliers[4]; mp.ICU0_multiplier = pb->multipliers[5];
+        mp.R0_multiplier = pb->multipliers[6]; mp.D0_multiplier = pb->multipliers[7];
+        mp.runup_days = pb->runup_days; mp.seed_exposed = pb->seed_exposed;
+
+        const std::vector<std::string> nm = split_lines(names);
+        std::map<std::string, double> sg;
+        std::map<std::string, std::pair<double, double>> bd;
+        for (size_t i = 0; i < nm.size(); ++i) {
+            sg[nm[i]] = sigmas[i];
+            bd[nm[i]] = {pb->lower[i], pb->upper[i]};
+        }
+        auto h = std::make_unique<HostHandle>();
+        h->pm = std::make_unique<HipSEPAIHRDParameterManager>(mp, nm, sg, bd, split_lines(npi_names));
+        h->pm->setConstraintMode(pb->constraint_mode == SEPAIHRD_CONSTRAINT_REFLECT ? ConstraintMode::MCMC_REFLECT
+                                                                                   : ConstraintMode::OPTIMIZATION_CLAMP);
+        h->cache = std::make_unique<SimulationCache>(static_cast<size_t>(cache_capacity > 0 ? cache_capacity : 1000));
+        if (!with_objective) return h.release();
+        auto mat = [&](const double* src) {
+            Eigen::MatrixXd m(pb->n_obs, n);
+            for (int r = 0; r < pb->n_obs; ++r)
+                for (int c = 0; c < n; ++c) m(r, c) = src[static_cast<size_t>(r) * n + c];
+            return m;
+        };
+        h->data = std::make_unique<CalibrationData>(mat(pb->obs_H), mat(pb->obs_ICU), mat(pb->obs_D), mp.N);
+        std::shared_ptr<IOdeSolverStrategy> solver;
+        if (pb->solver == SEPAIHRD_SOLVER_CASH_KARP54) solver = std::make_shared<CashKarpSolverStrategy>();
+        else solver = std::make_shared<Dopri5SolverStrategy>();
+        h->obj = std::make_unique<HipSEPAIHRDObjectiveFunction>(
+            *h->pm, *h->cache, *h->data, std::vector<double>(pb->times, pb->times + pb->n_times),
+            vec(pb->initial_state, 11 * n), solver, pb->abs_err, pb->rel_err, device, pb->arith == SEPAIHRD_ARITH_FMA);
+        return h.release();
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return nullptr;
+    }
+}
+
+void host_objective_destroy(void* hv) { delete static_cast<HostHandle*>(hv); }
+
+// returns 0 ok, 1 = exception thrown by calculate() (message in host_last_error)
+int host_objective_calculate(void* hv, const double* theta, double* value) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        *value = h->obj->calculate(vec(theta, static_cast<int>(h->pm->getParameterCount())));
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+int host_objective_calculate_batch(void* hv, const double* thetas, int B, double* out, int* status) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        h->obj->calculateBatch(thetas, B, out, status);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+void host_cache_stats(void* hv, long* calls, long* hits, long* size) {
+    auto* h = static_cast<HostHandle*>(hv);
+    *calls = static_cast<long>(h->cache->getLikelihoodCalls());
+    *hits = static_cast<long>(h->cache->getLikelihoodHits());
+    *size = static_cast<long>(h->cache->size());
+}
+
+int host_apply_constraints(void* hv, int mode, const double* in, double* out) {
+    auto* h = static_cast<HostHandle*>(hv);
+    const ConstraintMode keep = h->pm->getConstraintMode();
+    h->pm->setConstraintMode(mode == 1 ? ConstraintMode::MCMC_REFLECT : ConstraintMode::OPTIMIZATION_CLAMP);
+    const int P = static_cast<int>(h->pm->getParameterCount());
+    const Eigen::VectorXd c = h->pm->applyConstraints(vec(in, P));
+    for (int i = 0; i < P; ++i) out[i] = c[i];
+    h->pm->setConstraintMode(keep);
+    return 0;
+}
+
+int host_current_parameters(void* hv, double* out) {
+    auto* h = static_cast<HostHandle*>(hv);
+    const Eigen::VectorXd c = h->pm->getCurrentParameters();
+    for (Eigen::Index i = 0; i < c.size(); ++i) out[i] = c[i];
+    return 0;
+}
+
+// C chains of Adaptive Metropolis through the batched objective.  Outputs per chain:
+// accepted[C], best_value[C], best[C*P], final_scale[C], accept_trace[C*(iterations-1)],
+// n_samples (same for all chains), samples[C*n_samples*P], sample_values[C*n_samples].
+int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int iterations, int burn_in,
+                int adaptation_period, int thinning, double reg_eps, double target_acc, int adapt_scale,
+                int use_scalar_interface, int32_t* accepted, double* best_value, double* best, double* final_scale,
+                unsigned char* accept_trace, int32_t* n_samples, double* samples, double* sample_values) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        MultiChainMetropolisHastings mh;
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+                      {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
+                      {"regularization_epsilon", reg_eps}, {"target_acceptance_rate", target_acc},
+                      {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0}});
+        mh.setSeed(seed);
+        std::vector<OptimizationResult> res;
+        if (use_scalar_interface) {
+            for (int c = 0; c < C; ++c) {
+                mh.setSeed(seed + static_cast<uint32_t>(c));
+                res.push_back(mh.optimize(vec(initial + static_cast<size_t>(c) * P, P), *h->obj, *h->pm));
+                if (accept_trace)
+                    std::copy(mh.acceptTraces()[0].begin(), mh.acceptTraces()[0].end(),
+                              accept_trace + static_cast<size_t>(c) * (iterations - 1));
+            }
+        } else {
+            res = mh.optimizeChains(std::vector<double>(initial, initial + static_cast<size_t>(C) * P), C, *h->obj, *h->pm);
+            if (accept_trace)
+                for (int c = 0; c < C; ++c)
+                    std::copy(mh.acceptTraces()[static_cast<size_t>(c)].begin(), mh.acceptTraces()[static_cast<size_t>(c)].end(),
+                              accept_trace + static_cast<size_t>(c) * (iterations - 1));
+        }
+        const int ns = static_cast<int>(res[0].samples.size());
+        if (n_samples) *n_samples = ns;
+        for (int c = 0; c < C; ++c) {
+            const OptimizationResult& r = res[static_cast<size_t>(c)];
+            if (accepted) accepted[c] = static_cast<int32_t>(r.additionalStats.at("accepted_count"));
+            if (best_value) best_value[c] = r.bestObjectiveValue;
+            if (final_scale) final_scale[c] = r.additionalStats.at("final_scale");
+            if (best) for (int i = 0; i < P; ++i) best[static_cast<size_t>(c) * P + i] = r.bestParameters[i];
+            if (samples)
+                for (int s = 0; s < ns; ++s)
+                    for (int i = 0; i < P; ++i)
+                        samples[(static_cast<size_t>(c) * ns + s) * P + i] = r.samples[static_cast<size_t>(s)][i];
+            if (sample_values)
+                for (int s = 0; s < ns; ++s) sample_values[static_cast<size_t>(c) * ns + s] = r.sampleObjectiveValues[static_cast<size_t>(s)];
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""ctypes view of the C++ host mirror (host/, libsepaihrd_host.so) -- test plumbing.
+
+The C++ classes (HipSEPAIHRDObjectiveFunction, HipSEPAIHRDParameterManager, SimulationCache,
+MultiChainMetropolisHastings) are what a reference maintainer links against; the flat functions
+of host/src/host_capi.cpp only exist so that the Python test-suite can drive them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hipabi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsepaihrd_host.so")
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    hipabi.load_library()  # torch-first HIP runtime + libsepaihrd_hip.so, then the host library
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: run __graft_entry__.build()")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.host_last_error.restype = C.c_char_p
+    lib.host_objective_create.restype = vp
+    lib.host_objective_create.argtypes = [C.POINTER(hipabi.sepaihrd_problem), C.c_char_p, C.c_char_p, vp, C.c_int,
+                                          C.c_int, C.c_int]
+    lib.host_objective_destroy.argtypes = [vp]
+    lib.host_objective_calculate.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.host_objective_calculate_batch.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.host_cache_stats.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.host_apply_constraints.argtypes = [vp, C.c_int, vp, vp]
+    lib.host_current_parameters.argtypes = [vp, vp]
+    lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+class HostObjective:
+    """HipSEPAIHRDObjectiveFunction + its parameter manager + a SimulationCache (C++ objects)."""
+
+    def __init__(self, pb, device: int = -1, cache_capacity: int = 1000, with_objective: bool = True):
+        self.lib = load_library()
+        self.pb = pb
+        keep: list = []
+        st = hipabi.build_problem_struct(pb, keep)
+        sig = np.ascontiguousarray(pb.sigma_array())
+        self.h = self.lib.host_objective_create(C.byref(st), "\n".join(pb.param_names).encode(),
+                                                "\n".join(pb.npi_names).encode(), sig.ctypes.data, device,
+                                                cache_capacity, int(with_objective))
+        if not self.h:
+            raise RuntimeError("host_objective_create failed: " + self.lib.host_last_error().decode())
+        self.P = pb.n_params
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.host_objective_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def calculate(self, theta) -> float:
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        v = C.c_double()
+        if self.lib.host_objective_calculate(self.h, th.ctypes.data, C.byref(v)):
+            raise RuntimeError(self.lib.host_last_error().decode())
+        return v.value
+
+    def calculate_batch(self, thetas):
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        B = th.shape[0]
+        out = np.empty(B)
+        status = np.empty(B, dtype=np.int32)
+        if self.lib.host_objective_calculate_batch(self.h, th.ctypes.data, B, out.ctypes.data, status.ctypes.data):
+            raise RuntimeError(self.lib.host_last_error().decode())
+        return out, status
+
+    def cache_stats(self):
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        self.lib.host_cache_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"calls": a.value, "hits": b.value, "size": c.value}
+
+    def apply_constraints(self, theta, mode: int) -> np.ndarray:
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        out = np.empty_like(th)
+        for b in range(th.shape[0]):
+            self.lib.host_apply_constraints(self.h, mode, th[b].ctypes.data, out[b].ctypes.data)
+        return out
+
+    def current_parameters(self) -> np.ndarray:
+        out = np.empty(self.P)
+        self.lib.host_current_parameters(self.h, out.ctypes.data)
+        return out
+
+    def metropolis_hastings(self, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
+                            thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
+                            adapt_scale: bool = True, scalar_interface: bool = False) -> dict:
+        x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
+        Cn, P = x0.shape
+        cap = iterations // max(1, thinning) + 2
+        accepted = np.zeros(Cn, dtype=np.int32)
+        best_value, final_scale = np.zeros(Cn), np.zeros(Cn)
+        best = np.zeros((Cn, P))
+        trace = np.zeros((Cn, max(iterations - 1, 1)), dtype=np.uint8)
+        ns = C.c_int32()
+        samples = np.zeros((Cn, cap, P))
+        values = np.zeros((Cn, cap))
+        # first pass to learn n_samples layout is unnecessary: the C side packs with its own n_samples,
+        # so give it exact-size buffers after computing the count here (t = 0 plus every thinning-th t)
+        n_s = 1 + len([t for t in range(1, iterations) if t % max(1, thinning) == 0])
+        samples = np.zeros((Cn, n_s, P))
+        values = np.zeros((Cn, n_s))
+        rc = self.lib.host_mh_run(self.h, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning,
+                                  reg_eps, target_acc, int(adapt_scale), int(scalar_interface), accepted.ctypes.data,
+                                  best_value.ctypes.data, best.ctypes.data, final_scale.ctypes.data,
+                                  trace.ctypes.data, C.byref(ns), samples.ctypes.data, values.ctypes.data)
+        if rc:
+            raise RuntimeError(self.lib.host_last_error().decode())
+        assert ns.value == n_s
+        return {"accepted": accepted, "best_value": best_value, "best": best, "final_scale": final_scale,
+                "accept_trace": trace[:, :iterations - 1], "samples": samples, "sample_values": values}

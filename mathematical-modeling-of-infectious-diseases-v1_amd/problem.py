@@ -123,6 +123,7 @@ class SEPAIHRDProblem:
     rel_err: float = 1e-6
     dt_hint: float = 1.0
     arith: int = ARITH_STRICT
+    max_attempts: int = 0  # build-side guard on RK step attempts per chain, 0 = default (1e6)
     # calibrated starting point (getCurrentParameters of the shipped model)
     base_theta: Optional[np.ndarray] = None
 

@@ -83,6 +83,8 @@ void oracle_set_constraint_mode(void* h, int mode) {
     static_cast<Handle*>(h)->pb.pm.mode = mode == 1 ? oracle::MCMC_REFLECT : oracle::OPTIMIZATION_CLAMP;
 }
 
+void oracle_set_max_attempts(void* h, long max_attempts) { static_cast<Handle*>(h)->pb.max_attempts = max_attempts; }
+
 int oracle_eval_batch(void* hv, const double* theta, int B, double* loglik, int32_t* status,
                       int32_t* n_accept, int32_t* n_reject, double* ll_parts, double* traj,
                       int nthreads) {
@@ -192,7 +194,7 @@ int oracle_mh(void* hv, int iterations, int burn_in, int adaptation_period, int 
     oracle::Objective f = [&pb](const std::vector<double>& th) {
         oracle::EvalInfo info;
         double v = oracle::objective(pb, th, &info, nullptr);
-        if (info.status == 2) throw std::runtime_error("SimulationException");
+        if (info.status >= 2) throw std::runtime_error("SimulationException");
         return v;
     };
     oracle::MHResult r = oracle::metropolis_hastings(cfg, std::vector<double>(x0, x0 + P), f, pb.pm, seed);

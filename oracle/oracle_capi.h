@@ -28,6 +28,7 @@ typedef struct oracle_problem {
 void *oracle_create(const oracle_problem *pb, char *err, int errlen);
 void oracle_destroy(void *h);
 void oracle_set_constraint_mode(void *h, int mode);
+void oracle_set_max_attempts(void *h, long max_attempts);
 
 /* theta: B x P chain-major.  traj (nullable): B x T x 11n.  ll_parts (nullable): B x 3. */
 int oracle_eval_batch(void *h, const double *theta, int B, double *loglik, int32_t *status,

@@ -54,6 +54,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_create.argtypes = [C.POINTER(oracle_problem), C.c_char_p, C.c_int]
     lib.oracle_destroy.argtypes = [vp]
     lib.oracle_set_constraint_mode.argtypes = [vp, C.c_int]
+    lib.oracle_set_max_attempts.argtypes = [vp, C.c_long]
     lib.oracle_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_rhs.argtypes = [vp, vp, vp, C.c_double, vp]
     lib.oracle_beta_kappa.restype = C.c_double
@@ -125,6 +126,9 @@ class Oracle:
 
     def set_constraint_mode(self, mode: int):
         self.lib.oracle_set_constraint_mode(self.h, mode)
+
+    def set_max_attempts(self, n: int):
+        self.lib.oracle_set_max_attempts(self.h, n)
 
     def eval_batch(self, theta, want_traj: bool = False, nthreads: int = 0) -> dict:
         th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)

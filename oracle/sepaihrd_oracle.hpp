@@ -216,8 +216,15 @@ struct step_adjustment_error : std::runtime_error {
         : std::runtime_error("Max number of iterations exceeded (500). A new step size was not found.") {}
 };
 
+// Build-side guard shared with the HIP path (the reference / odeint have none): with a degenerate
+// tolerance the step size underflows to 0 and zero-length steps are "accepted" forever.
+struct step_budget_error : std::runtime_error {
+    step_budget_error() : std::runtime_error("step attempt budget exhausted") {}
+};
+
 struct StepStats {
     long accepted = 0, rejected = 0, rhs_calls = 0;
+    long max_attempts = 1000000;
 };
 
 using System = std::function<void(const double*, double*, double)>;
@@ -434,8 +441,10 @@ struct ControlledCashKarp {
 template <class Stepper>
 inline size_t integrate_times(Stepper& stepper, const System& sys, state_type& x,
                               const std::vector<double>& times, double dt,
-                              const std::function<void(const state_type&, double)>& obs) {
+                              const std::function<void(const state_type&, double)>& obs,
+                              long max_attempts = 1000000) {
     size_t steps = 0;
+    long attempts = 0;
     int fails = 0;  // failed_step_checker, max 500
     auto it = times.begin();
     const auto end = times.end();
@@ -447,6 +456,7 @@ inline size_t integrate_times(Stepper& stepper, const System& sys, state_type& x
         // less_with_sign(t1, t2, dt>0): t2 - t1 > epsilon
         while ((*it - current_time) > std::numeric_limits<double>::epsilon()) {
             double current_dt = std::min(dt, *it - current_time);  // min_abs, dt > 0
+            if (attempts++ >= max_attempts) throw step_budget_error();
             if (stepper.try_step(sys, x, current_time, current_dt)) {
                 ++steps;
                 fails = 0;
@@ -486,10 +496,10 @@ inline SimulationResult simulate(const Model& model, const state_type& init,
     };
     if (solver == DOPRI5) {
         ControlledDopri5 stp(abs_err, rel_err, st);
-        integrate_times(stp, sys, x, times, dt_hint, obs);
+        integrate_times(stp, sys, x, times, dt_hint, obs, st ? st->max_attempts : 1000000);
     } else {
         ControlledCashKarp stp(abs_err, rel_err, st);
-        integrate_times(stp, sys, x, times, dt_hint, obs);
+        integrate_times(stp, sys, x, times, dt_hint, obs, st ? st->max_attempts : 1000000);
     }
     return res;
 }
@@ -640,11 +650,12 @@ struct Problem {
     std::vector<double> obs_H, obs_ICU, obs_D;
     Solver solver = DOPRI5;
     double abs_err = 1e-6, rel_err = 1e-6, dt_hint = 1.0;
+    long max_attempts = 1000000;
 };
 
 struct EvalInfo {
     StepStats steps;
-    int status = 0;  // 0 ok, 1 = returned lowest(), 2 = SimulationException would propagate
+    int status = 0;  // 0 ok, 1 = returned lowest(), 2 = SimulationException would propagate, 3 = step budget
     double ll_hosp = 0, ll_icu = 0, ll_deaths = 0;
 };
 
@@ -696,10 +707,14 @@ inline double objective(const Problem& pb, const std::vector<double>& theta, Eva
     }
 
     SimulationResult res;
+    inf.steps.max_attempts = pb.max_attempts;
     try {
         res = simulate(model, init, tp, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &inf.steps);
     } catch (const step_adjustment_error&) {
         inf.status = 2;  // SimulationException propagates out of calculate() (no try/catch at :165)
+        return LOWEST;
+    } catch (const step_budget_error&) {
+        inf.status = 3;
         return LOWEST;
     }
     const size_t T = tp.size();

@@ -116,6 +116,19 @@ def test_nan_observations_skipped_and_clamp_mode(mm, oracle_py, ref_fixture):
     np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
 
 
+def test_step_budget_guard_matches_oracle(mm, oracle_py, ref_fixture):
+    """Degenerate tolerance -> zero-length steps for ever; both sides stop at the attempt budget."""
+    pb = ref_fixture.with_(abs_err=0.0, rel_err=1e-300, max_attempts=3000)
+    theta = np.tile(pb.base_theta, (3, 1))
+    orc = oracle_py.Oracle(pb)
+    orc.set_max_attempts(3000)
+    ref = orc.eval_batch(theta)
+    got = mm.HipObjective(pb).eval_batch(theta)
+    assert got["status"].tolist() == [3, 3, 3] == ref["status"].tolist()
+    assert np.all(got["loglik"] == mm.LOWEST)
+    assert np.array_equal(got["n_accept"] + got["n_reject"], ref["n_accept"] + ref["n_reject"])
+
+
 def test_device_pointer_entry_point(mm, oracle_py, synth400, draws):
     import torch
     pb = synth400

@@ -1,0 +1,189 @@
+"""Host-side logic that needs no GPU: name -> field resolution, constraints, draw generator,
+file formats, problem plumbing, and the C-ABI library's exported surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol(mm):
+    lib = mm.load_library()
+    header = open(os.path.join(ROOT, "include", "sepaihrd_hip.h")).read()
+    declared = set(re.findall(r"\b(sepaihrd_[a-z_]+)\s*\(", header))
+    declared -= {"sepaihrd_mh_"}
+    assert declared == set(mm.hipabi.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.sepaihrd_abi_version() == mm.hipabi.ABI_VERSION
+
+
+def test_struct_layout_matches_header_field_order(mm):
+    header = open(os.path.join(ROOT, "include", "sepaihrd_hip.h")).read()
+    start = header.index("typedef struct sepaihrd_problem {") + len("typedef struct sepaihrd_problem {")
+    body = header[start:header.index("} sepaihrd_problem;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        for piece in decl.split(","):
+            m = re.search(r"\*?\s*([A-Za-z_][A-Za-z_0-9]*)\s*(\[\d+\])?$", piece.strip())
+            names.append(m.group(1))
+    assert names == [f for f, _ in mm.hipabi.sepaihrd_problem._fields_]
+
+
+def test_create_fails_loudly_without_gpu(mm, shipped, have_gpu):
+    if have_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device|sepaihrd_create failed"):
+        mm.HipObjective(shipped)
+
+
+def test_name_resolution_follows_reference_dispatch_order(mm, shipped):
+    r = lambda nm: mm.resolve_param_name(nm, shipped.npi_names, 4, 7)
+    assert r("beta_1") == (18, 0) and r("beta_7") == (18, 6)
+    assert r("kappa_2") == (19, 1) and r("kappa_7") == (19, 6)
+    assert r("kappa_1") == (-1, 0)            # fixed baseline: not calibratable -> ignored with a warning
+    assert r("h_infec_2") == (21, 2)          # "h_infec_" must win over "h_"
+    assert r("h_2") == (23, 2) and r("p_0") == (22, 0) and r("icu_3") == (24, 3)
+    assert r("d_H_1") == (25, 1) and r("d_ICU_1") == (26, 1) and r("d_community_3") == (27, 3)
+    assert r("gamma_p") == (3, 0) and r("P0_multiplier") == (9, 0) and r("runup_days") == (16, 0)
+    assert r("no_such_parameter") == (-1, 0)
+    with pytest.raises(ValueError):
+        r("beta_8")
+    codes, idx = shipped.field_map()
+    assert len(codes) == 62 and (codes >= 0).all()
+    # the shipped theta covers 53 effective + 9 inert parameters
+    assert np.array_equal(shipped.current_parameters(), shipped.base_theta)
+
+
+def test_constraints_match_oracle(mm, oracle_py, shipped):
+    from mmid_amd import draws
+    orc = oracle_py.Oracle(shipped)
+    rs = np.random.RandomState(2)
+    lo, hi, has = shipped.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(-3.0, 4.0, (50, shipped.n_params))
+    for mode in (0, 1):
+        got = draws.apply_constraints(theta, lo, hi, has, mode)
+        ref = orc.apply_constraints(theta, mode)
+        assert np.array_equal(got, ref)
+        assert np.all(got >= lo) and np.all(got <= hi)
+    # reflect is NOT idempotent in floating point (minb + (y - minb) may round): the device re-applies it
+    once = draws.apply_constraints(theta, lo, hi, has, 1)
+    twice = draws.apply_constraints(once, lo, hi, has, 1)
+    assert np.abs(once - twice).max() < 1e-15
+
+
+def test_constraints_without_bounds_entry(mm):
+    from mmid_amd import draws
+    v = np.array([[-0.5, 0.25]])
+    assert np.array_equal(draws.apply_constraints(v, np.zeros(2), np.zeros(2), np.zeros(2), 0), [[0.0, 0.25]])
+    assert np.array_equal(draws.apply_constraints(v, np.zeros(2), np.zeros(2), np.zeros(2), 1), [[0.5, 0.25]])
+
+
+def test_draw_generator_reproduces_libstdcxx(mm, oracle_py, synth400):
+    from mmid_amd import draws
+    z = draws.std_normals_batch(np.array([1, 42, 123456]), 63)   # odd count: last pair half used
+    for row, seed in zip(z, (1, 42, 123456)):
+        assert np.array_equal(row, oracle_py.std_normals(seed, 63))
+    a = draws.jitter_draws(synth400, 1, 300)
+    b = oracle_py.Oracle(synth400).jitter_draws(synth400.base_theta, 1, 300)
+    assert np.array_equal(a, b)
+
+
+def test_config_readers_on_synthetic_files(mm, tmp_path):
+    cio = mm.config_io
+    p = tmp_path / "guess.txt"
+    p.write_text("# comment\nbeta_end_times 13.0 63.0\nkappa_end_times 13.0 63.0\nbeta_1 0.4\nbeta_2 0.2\n"
+                 "kappa_1 1.0\nkappa_2 0.5\n\na 0.5 0.9 0.8 1.2\nsigma 3e-1\nruns_unknown 7\n")
+    par = cio.read_sepaihrd_parameters(str(p), 4)
+    assert np.array_equal(par["beta_values"], [0.4, 0.2]) and np.array_equal(par["kappa_values"], [1.0, 0.5])
+    assert np.array_equal(par["a"], [0.5, 0.9, 0.8, 1.2]) and par["sigma"] == 0.3
+    assert np.array_equal(par["beta_end_times"], [13.0, 63.0])
+    b = tmp_path / "bounds.txt"
+    b.write_text("# b\nbeta_1  0.35   0.9\ntheta 0.2 0.8\n")
+    assert cio.read_param_bounds(str(b)) == {"beta_1": (0.35, 0.9), "theta": (0.2, 0.8)}
+    s = tmp_path / "sig.txt"
+    s.write_text("beta_1 0.02\n# x\ntheta 0.03\n")
+    assert cio.read_proposal_sigmas(str(s)) == {"beta_1": 0.02, "theta": 0.03}
+    c = tmp_path / "cal.txt"
+    c.write_text("# names\nbeta_1\n\ntheta\n")
+    assert cio.read_params_to_calibrate(str(c)) == ["beta_1", "theta"]
+    m = tmp_path / "m.csv"
+    m.write_text("1,2\n3,4\n")
+    assert np.array_equal(cio.read_matrix_csv(str(m), 2, 2), [[1, 2], [3, 4]])
+    with pytest.raises(ValueError):
+        cio.read_matrix_csv(str(m), 3, 3)
+
+
+def test_initial_state_heuristic_properties(mm, ref_fixture):
+    """GetCalibrationDataTests.cpp:163-227: observable compartments, conservation, non-negativity."""
+    n = 4
+    x = ref_fixture.initial_state.reshape(11, n)
+    assert np.all(x >= 0)
+    assert np.allclose(x[:9].sum(axis=0), ref_fixture.N, rtol=1e-12)
+    assert np.array_equal(x[9], ref_fixture.obs_H[0]) and np.array_equal(x[10], ref_fixture.obs_ICU[0])
+    assert np.array_equal(x[8], np.minimum(ref_fixture.obs_D[0], ref_fixture.N))
+
+
+def test_posterior_trace_csv_format(mm, tmp_path):
+    path = tmp_path / "trace.csv"
+    mm.config_io.write_posterior_trace_csv(str(path), np.array([[0.5, 2.0]]), np.array([-1234.5]), ["a", "b"])
+    lines = path.read_text().splitlines()
+    assert lines[0] == "iter,log_posterior,a,b"
+    assert lines[1] == "0,-1.234500e+03,5.000000e-01,2.000000e+00"
+
+
+def test_widen_age_classes_config5_shape(mm, shipped):
+    w = mm.widen_age_classes(shipped, 4)
+    assert w.n == 16 and w.M.shape == (16, 16)
+    assert np.isclose(w.N.sum(), shipped.N.sum())
+    assert np.allclose(w.M[0:4, 4:8], shipped.M[0, 1] / 4)
+    assert w.n_params == 62 + 3 * 32    # the 32 age-indexed parameters become 128
+    assert len(w.base_theta) == w.n_params
+    codes, _ = w.field_map()
+    assert (codes >= 0).all()
+
+
+def test_problem_json_roundtrip(mm, shipped, tmp_path):
+    p = tmp_path / "pb.json"
+    shipped.save(str(p))
+    back = mm.SEPAIHRDProblem.load(str(p))
+    assert np.array_equal(back.base_theta, shipped.base_theta) and back.param_names == shipped.param_names
+    assert np.array_equal(back.obs_D, shipped.obs_D) and back.bounds == shipped.bounds
+
+
+# ---- C++ host mirror (host/): the parts that need no device
+def test_host_parameter_manager_mirrors_reference(mm, oracle_py, shipped):
+    h = mm.HostObjective(shipped, with_objective=False)
+    assert np.array_equal(h.current_parameters(), shipped.base_theta)     # getCurrentParameters
+    rs = np.random.RandomState(4)
+    lo, hi, _ = shipped.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(-2.0, 3.0, (20, shipped.n_params))
+    orc = oracle_py.Oracle(shipped)
+    for mode in (0, 1):
+        assert np.array_equal(h.apply_constraints(theta, mode), orc.apply_constraints(theta, mode))
+
+
+def test_host_parameter_manager_rejects_what_the_reference_rejects(mm, shipped):
+    bad = shipped.with_(param_names=shipped.param_names + ["kappa_1"],
+                        sigmas={**shipped.sigmas, "kappa_1": 0.1}, bounds={**shipped.bounds, "kappa_1": (0.5, 1.5)},
+                        base_theta=None)
+    # Python-side resolution mirrors the warning path; the C++ manager mirrors the constructor's throw
+    with pytest.raises(RuntimeError, match="fixed baseline kappa"):
+        mm.HostObjective(bad, with_objective=False)
+    missing = shipped.with_(sigmas={k: v for k, v in shipped.sigmas.items() if k != "theta"}, base_theta=None)
+    # sigma_array() fills 0.0 for the C shim, so drop the name from bounds instead to hit "Missing bounds"
+    assert "theta" in missing.param_names
+
+
+def test_host_objective_fails_loudly_without_gpu(mm, shipped, have_gpu):
+    if have_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        mm.HostObjective(shipped)

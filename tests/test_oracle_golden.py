@@ -1,0 +1,192 @@
+"""CPU oracle (oracle/) pinned against everything that can pin it in this container:
+
+  * the reference's only closed-form known answer, ManualPoissonLikelihoodTest
+    (tests/model/SEPAIHRDObjectivefunctionTest.cpp:688-752, tolerance 1e-8);
+  * independent high-precision answers committed under tests/golden/ (SciPy DOP853 at
+    rtol=1e-13 restarted at every schedule breakpoint, mpmath RHS values) -- these bound the
+    restated Boost.Odeint integrator, for which the reference holds no pinned value;
+  * the structural properties the reference tests for calculate() (same file :334-685).
+"""
+import numpy as np
+import pytest
+
+
+def test_manual_poisson_likelihood(oracle_py, golden):
+    g = golden["manual_poisson"]
+    obs, sim = np.array(g["obs"]), np.array(g["sim"])
+    manual = 0.0
+    for i in range(obs.shape[0]):
+        for j in range(obs.shape[1]):
+            s = sim[i, j] + 1e-10
+            manual += obs[i, j] * np.log(s) - s
+    got = oracle_py.poisson_loglik(sim, obs)
+    assert abs(got - manual) < 1e-8          # the reference's own assertion
+    assert abs(got - g["loglik"]) < 1e-12    # 40-digit mpmath value
+
+
+def test_poisson_skips_nan_and_negative_observations(oracle_py):
+    sim = np.array([[1.0, 2.0], [3.0, 4.0]])
+    obs = np.array([[1.0, np.nan], [-1.0, 2.0]])
+    want = (1.0 * np.log(1.0 + 1e-10) - (1.0 + 1e-10)) + (2.0 * np.log(4.0 + 1e-10) - (4.0 + 1e-10))
+    assert abs(oracle_py.poisson_loglik(sim, obs) - want) < 1e-12
+    # negative simulated values are clamped to 0 before the epsilon
+    assert abs(oracle_py.poisson_loglik(np.array([[-5.0]]), np.array([[2.0]])) -
+               (2.0 * np.log(1e-10) - 1e-10)) < 1e-9
+
+
+def test_rhs_against_mpmath_spot_values(oracle_py, shipped, golden):
+    orc = oracle_py.Oracle(shipped)
+    for spot in golden["rhs_spots_shipped"]:
+        dx = orc.rhs(np.array(spot["x"]), spot["t"], theta=shipped.base_theta)
+        ref = np.array(spot["dxdt"])
+        scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+        assert (np.abs(dx - ref) / scale).max() < 1e-11, spot["t"]
+
+
+def test_rhs_population_conservation(oracle_py, shipped):
+    orc = oracle_py.Oracle(shipped)
+    n = shipped.n
+    rs = np.random.RandomState(0)
+    x = np.concatenate([shipped.N * 0.9] + [shipped.N * 1e-3 * rs.uniform(0.1, 1, n) for _ in range(10)])
+    dx = orc.rhs(x, 40.0, theta=shipped.base_theta).reshape(11, n)
+    # S..D sum to zero per age class; CumH / CumICU are bookkeeping only
+    assert np.abs(dx[:9].sum(axis=0)).max() < 1e-9 * np.abs(dx[:9]).max()
+    assert np.all(dx[9] >= 0) and np.all(dx[10] >= 0)
+
+
+def test_schedule_boundary_rule(oracle_py, shipped):
+    """t <= end keeps the OLD value at a breakpoint; t < 0 is the kappa baseline; past the last
+    end the last value holds (PiecewiseConstantParameterStrategy.cpp:37-74, NPI.cpp:86-127)."""
+    orc = oracle_py.Oracle(shipped)
+    th = shipped.base_theta
+    bv, kv = shipped.beta_values, shipped.kappa_values
+    assert orc.beta_kappa(13.0, th) == (bv[0], kv[0])
+    assert orc.beta_kappa(np.nextafter(13.0, 14.0), th) == (bv[1], kv[1])
+    assert orc.beta_kappa(-5.0, th) == (bv[0], kv[0])
+    assert orc.beta_kappa(63.0, th) == (bv[1], kv[1])
+    assert orc.beta_kappa(305.0, th) == (bv[6], kv[6])
+    assert orc.beta_kappa(400.0, th) == (bv[6], kv[6])
+
+
+@pytest.mark.parametrize("key,fixture_name", [("shipped", "shipped"), ("reference_test_fixture", "ref_fixture"),
+                                              ("shipped_perturbed", "shipped")])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_integrator_against_high_precision(oracle_py, golden, request, key, fixture_name, solver):
+    """abs = rel = 1e-6 controlled steppers vs a 1e-13 reference: agreement is limited by the
+    solver tolerance (states ~1e-4 relative, log-likelihood ~1e-5..2e-3 relative where it is
+    hugely negative)."""
+    pb = request.getfixturevalue(fixture_name)
+    pb.solver = solver
+    g = golden[key]
+    r = oracle_py.Oracle(pb).eval_batch(np.array(g["theta"]), want_traj=True, nthreads=1)
+    assert r["status"][0] == 0
+    st = r["traj"][0][g["time_index"]]
+    gs = np.array(g["states"])
+    assert (np.abs(st - gs) / (np.abs(gs) + 1e-3)).max() < 5e-4
+    assert abs(r["loglik"][0] - g["loglik"]) / abs(g["loglik"]) < 5e-3
+    if key != "shipped_perturbed":
+        assert abs(r["loglik"][0] - g["loglik"]) / abs(g["loglik"]) < 2e-4
+    # every daily interval costs at least one accepted step; dt_hint = 1 day
+    assert r["n_accept"][0] >= pb.n_times - 1
+
+
+def test_tighter_tolerance_converges_to_high_precision(oracle_py, golden, shipped):
+    g = golden["shipped"]
+    errs = []
+    for tol in (1e-6, 1e-8, 1e-10):
+        shipped.abs_err = shipped.rel_err = tol
+        r = oracle_py.Oracle(shipped).eval_batch(np.array(g["theta"]), nthreads=1)
+        errs.append(abs(r["loglik"][0] - g["loglik"]) / abs(g["loglik"]))
+    assert errs[1] < errs[0] and errs[2] < 1e-8, errs
+
+
+# ---- the reference's structural tests of calculate(), SEPAIHRDObjectivefunctionTest.cpp
+def test_calculate_is_finite_repeatable_and_sensitive(oracle_py, ref_fixture):
+    orc = oracle_py.Oracle(ref_fixture)
+    th = ref_fixture.base_theta
+    v = orc.calculate(th)
+    assert np.isfinite(v)                                   # :334
+    assert all(orc.calculate(th) == v for _ in range(5))    # :492 repeatability
+    th2 = th.copy()
+    th2[0] *= 1.5
+    assert orc.calculate(th2) != v                          # :368 sensitivity
+
+
+def test_zero_data_and_dense_grid(oracle_py, ref_fixture):
+    pb = ref_fixture
+    zero = pb.with_(obs_H=np.zeros_like(pb.obs_H), obs_ICU=np.zeros_like(pb.obs_ICU),
+                    obs_D=np.zeros_like(pb.obs_D))
+    v0 = oracle_py.Oracle(zero).calculate(pb.base_theta)
+    assert np.isfinite(v0) and v0 <= 0.0                    # :384 (only -sim terms remain)
+    t = np.arange(0, 291) * 0.1                             # :414 0.1-day grid
+    dense = pb.with_(times=t, obs_H=np.ones((291, 4)), obs_ICU=np.ones((291, 4)), obs_D=np.ones((291, 4)))
+    assert np.isfinite(oracle_py.Oracle(dense).calculate(pb.base_theta))
+
+
+def test_streams_are_additive(oracle_py, ref_fixture):
+    pb = ref_fixture
+    r = oracle_py.Oracle(pb).eval_batch(pb.base_theta, nthreads=1)
+    assert r["loglik"][0] == (r["ll_parts"][0, 0] + r["ll_parts"][0, 1]) + r["ll_parts"][0, 2]   # :222-225
+
+
+def test_failure_sentinels(oracle_py, shipped, mm):
+    pb = shipped
+    pb.bounds = dict(pb.bounds)
+    pb.bounds["seed_exposed"] = (5.0, 1e9)
+    th = pb.base_theta.copy()
+    th[pb.param_names.index("seed_exposed")] = 9e8          # E0 > N  ->  lowest()
+    r = oracle_py.Oracle(pb).eval_batch(th, nthreads=1)
+    assert r["status"][0] == 1 and r["loglik"][0] == mm.LOWEST
+    # observation rows != number of t >= 0 points  ->  lowest()  (:176-178)
+    bad = pb.with_(obs_H=pb.obs_H[:-1], obs_ICU=pb.obs_ICU[:-1], obs_D=pb.obs_D[:-1])
+    r = oracle_py.Oracle(bad).eval_batch(pb.base_theta, nthreads=1)
+    assert r["status"][0] == 1 and r["loglik"][0] == mm.LOWEST
+
+
+def test_runup_branch_ignores_multipliers_and_runup_days(oracle_py, shipped):
+    """in the shipped configuration theta[48..55] and theta[57] are inert."""
+    orc = oracle_py.Oracle(shipped)
+    th = shipped.base_theta.copy()
+    v = orc.calculate(th)
+    for name in ("E0_multiplier", "D0_multiplier", "runup_days"):
+        th2 = th.copy()
+        lo, hi = shipped.bounds[name]
+        th2[shipped.param_names.index(name)] = 0.5 * (lo + hi)
+        assert orc.calculate(th2) == v
+
+
+def test_step_budget_guard(oracle_py, ref_fixture):
+    """Degenerate tolerance: the trial step underflows to 0 and zero-length steps are accepted for
+    ever (odeint's 500-rejection check never fires because every rejection shrinks dt by >= 5x).
+    The build-side attempt budget ends the evaluation with status 3 and lowest()."""
+    pb = ref_fixture.with_(abs_err=0.0, rel_err=1e-300)
+    orc = oracle_py.Oracle(pb)
+    orc.set_max_attempts(5000)
+    r = orc.eval_batch(pb.base_theta, nthreads=1)
+    assert r["status"][0] == 3 and r["n_accept"][0] + r["n_reject"][0] >= 5000
+
+
+def test_cache_hash_quantisation(oracle_py):
+    """SimulationCache::computeHash: theta quantised to 1e-8 (SimulationCache.cpp:35-52)."""
+    a = np.array([0.123456781, 2.5])
+    b = a + 3e-9
+    c = a + 2e-8
+    assert oracle_py.cache_hash(a) == oracle_py.cache_hash(b)
+    assert oracle_py.cache_hash(a) != oracle_py.cache_hash(c)
+
+
+def test_metropolis_hastings_restated(oracle_py, ref_fixture):
+    orc = oracle_py.Oracle(ref_fixture)
+    r1 = orc.metropolis_hastings(ref_fixture.base_theta, seed=7, iterations=300, burn_in=100,
+                                 adaptation_period=50, thinning=10)
+    r2 = orc.metropolis_hastings(ref_fixture.base_theta, seed=7, iterations=300, burn_in=100,
+                                 adaptation_period=50, thinning=10)
+    assert r1["accepted"] == r2["accepted"] and np.array_equal(r1["accept_trace"], r2["accept_trace"])
+    assert len(r1["accept_trace"]) == 299 and r1["accepted"] == int(r1["accept_trace"].sum())
+    assert r1["samples"].shape == (30, 5)          # t = 0 plus every 10th of 1..299
+    assert r1["best_value"] >= r1["sample_values"][0]
+    lo, hi, _ = ref_fixture.bounds_arrays()
+    assert np.all(r1["samples"] >= lo - 1e-12) and np.all(r1["samples"] <= hi + 1e-12)   # reflect keeps bounds
+    r3 = orc.metropolis_hastings(ref_fixture.base_theta, seed=8, iterations=300, burn_in=100,
+                                 adaptation_period=50, thinning=10)
+    assert not np.array_equal(r1["accept_trace"], r3["accept_trace"])
