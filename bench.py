@@ -56,13 +56,27 @@ def problem_bytes(pb):
                 len(pb.kappa_values) * 2 + 3 * pb.n_params)
 
 
+def host_cpu_share(omp_max):
+    """Threads the CPU baseline may use: the process' CPU affinity, capped by a cgroup CPU quota when one
+    is set (a 1-GPU box grants a 16-CPU share of a 128-thread host)."""
+    n = min(omp_max, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    env_cap = os.environ.get("SEPAIHRD_CPU_THREADS")
+    return max(1, min(n, int(env_cap)) if env_cap else n)
+
+
 def cpu_baseline(pb, theta, budget_s):
     """Oracle (CPU restatement of the reference path, kind "port") on a bounded sample of the
     same draws, OpenMP over chains on all host cores.  Checker only: never the measured path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     orc = oracle_py.Oracle(pb)
-    cores = oracle_py.load().oracle_num_threads()
+    cores = host_cpu_share(oracle_py.load().oracle_num_threads())
     # single thread first: ~2 s
     t0 = time.perf_counter()
     orc.eval_batch(theta[:8], nthreads=1)

@@ -9,7 +9,7 @@ The directory name is not a Python identifier; import it through ``mmid_amd_load
 """
 from .problem import (SEPAIHRDProblem, resolve_param_name, widen_age_classes, SOLVER_DOPRI5,
                       SOLVER_CASH_KARP54, CONSTRAINT_CLAMP, CONSTRAINT_REFLECT, ARITH_STRICT, ARITH_FMA)
-from . import config_io, hipabi, hostabi, draws
+from . import config_io, hipabi, hostabi, draws, parallel
 from .hipabi import HipObjective, load_library, LIB_PATH, LOWEST
 from .hostabi import HostObjective
 

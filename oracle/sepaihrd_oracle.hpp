@@ -475,24 +475,33 @@ inline size_t integrate_times(Stepper& stepper, const System& sys, state_type& x
 // -----------------------------------------------------------------------------
 struct SimulationResult {
     std::vector<double> time_points;
-    std::vector<state_type> solution;
+    std::vector<double> flat;  // T x m, row = output time (one allocation instead of one per day)
+    size_t m = 0;
+    const double* row(size_t k) const { return flat.data() + k * m; }
 };
 
-inline SimulationResult simulate(const Model& model, const state_type& init,
-                                 const std::vector<double>& times, Solver solver, double dt_hint,
-                                 double abs_err, double rel_err, StepStats* st = nullptr) {
+// `res` is caller-provided scratch so that a worker thread reuses one buffer across evaluations
+// (a fresh >128 KB vector per call is an mmap + page faults under the process-wide mm lock, which
+// serialises OpenMP workers).
+inline void simulate(SimulationResult& res, const Model& model, const state_type& init,
+                     const std::vector<double>& times, Solver solver, double dt_hint,
+                     double abs_err, double rel_err, StepStats* st = nullptr) {
     if (static_cast<int>(init.size()) != NUM_COMPARTMENTS * model.P.n)
         throw std::invalid_argument("Simulator::run: initial state size mismatch");
     if (times.empty()) throw std::invalid_argument("Simulator::run: empty output time points");
     for (size_t i = 1; i < times.size(); ++i)
         if (times[i] <= times[i - 1])
             throw std::invalid_argument("Simulator::run: time points must be strictly increasing");
-    SimulationResult res;
+    res.m = init.size();
+    res.time_points.clear();
+    res.flat.clear();
+    res.time_points.reserve(times.size());
+    res.flat.reserve(times.size() * init.size());
     state_type x = init;
     System sys = [&model](const double* xs, double* dx, double t) { model.rhs(xs, dx, t); };
     auto obs = [&res](const state_type& s, double t) {
         res.time_points.push_back(t);
-        res.solution.push_back(s);
+        res.flat.insert(res.flat.end(), s.begin(), s.end());
     };
     if (solver == DOPRI5) {
         ControlledDopri5 stp(abs_err, rel_err, st);
@@ -501,7 +510,6 @@ inline SimulationResult simulate(const Model& model, const state_type& init,
         ControlledCashKarp stp(abs_err, rel_err, st);
         integrate_times(stp, sys, x, times, dt_hint, obs, st ? st->max_attempts : 1000000);
     }
-    return res;
 }
 
 // -----------------------------------------------------------------------------
@@ -706,10 +714,10 @@ inline double objective(const Problem& pb, const std::vector<double>& theta, Eva
         init[i] = model.P.N[i] - sum;
     }
 
-    SimulationResult res;
+    thread_local SimulationResult res;
     inf.steps.max_attempts = pb.max_attempts;
     try {
-        res = simulate(model, init, tp, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &inf.steps);
+        simulate(res, model, init, tp, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &inf.steps);
     } catch (const step_adjustment_error&) {
         inf.status = 2;  // SimulationException propagates out of calculate() (no try/catch at :165)
         return LOWEST;
@@ -718,21 +726,16 @@ inline double objective(const Problem& pb, const std::vector<double>& theta, Eva
         return LOWEST;
     }
     const size_t T = tp.size();
-    if (traj) {
-        traj->resize(T * NUM_COMPARTMENTS * n);
-        for (size_t k = 0; k < T; ++k)
-            std::copy(res.solution[k].begin(), res.solution[k].end(),
-                      traj->begin() + k * NUM_COMPARTMENTS * n);
-    }
+    if (traj) *traj = res.flat;
     if (num_obs_points != pb.num_obs_rows) { inf.status = 1; return LOWEST; }  // :176-178
 
     // :191-215 daily incidence from the cumulative compartments D (8n), CumH (9n), CumICU (10n)
     std::vector<double> sim_hosp(T * n), sim_icu(T * n), sim_deaths(T * n);
     auto diff = [&](std::vector<double>& out, int comp) {
-        for (int i = 0; i < n; ++i) out[i] = res.solution[0][comp * n + i] - init[comp * n + i];
+        for (int i = 0; i < n; ++i) out[i] = res.row(0)[comp * n + i] - init[comp * n + i];
         for (size_t k = 1; k < T; ++k)
             for (int i = 0; i < n; ++i)
-                out[k * n + i] = res.solution[k][comp * n + i] - res.solution[k - 1][comp * n + i];
+                out[k * n + i] = res.row(k)[comp * n + i] - res.row(k - 1)[comp * n + i];
         for (double& v : out) v = std::max(v, 0.0);  // cwiseMax(0.0)
     };
     diff(sim_hosp, 9);
