@@ -33,12 +33,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU per step")
-    ap.add_argument("--solver", choices=["dopri5", "cashkarp"], default="dopri5")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c5"], default="c1",
+                    help="BASELINE.json configs: c1 = configs[1] (default), c2 = Cash-Karp 65 536 chains, "
+                         "c3 = 32 768 chains/GPU, c5 = 16 age groups x 1 000 days")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU per step (0 = the workload's)")
+    ap.add_argument("--solver", choices=["dopri5", "cashkarp", "workload"], default="workload")
     ap.add_argument("--arith", choices=["strict", "fma"], default="fma",
                     help="fma: mul+add contraction on (production mode, parity-tested to the 1e-6 north-star "
                          "tolerance); strict: the CPU build's operation sequence (bit-level parity mode)")
-    ap.add_argument("--problem", default="synth_400d_n4.json")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
     return ap.parse_args()
@@ -121,11 +123,15 @@ def main():
     mm = mmid_amd_loader.load()
     from mmid_amd import draws
 
-    pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", args.problem))
-    pb.solver = mm.SOLVER_DOPRI5 if args.solver == "dopri5" else mm.SOLVER_CASH_KARP54
+    from mmid_amd import workloads
+    pb = workloads.build(args.workload, os.path.join(ROOT, "tests", "golden"),
+                         hip_factory=lambda q: mm.HipObjective(q, device=local_rank))
+    if args.solver != "workload":
+        pb.solver = mm.SOLVER_DOPRI5 if args.solver == "dopri5" else mm.SOLVER_CASH_KARP54
+    solver_name = "dopri5" if pb.solver == mm.SOLVER_DOPRI5 else "cashkarp"
     pb.arith = mm.ARITH_STRICT if args.arith == "strict" else mm.ARITH_FMA
     pb.constraint_mode = mm.CONSTRAINT_REFLECT
-    B, K, W = args.chains, args.steps, args.warmup
+    B, K, W = (args.chains or workloads.DEFAULT_CHAINS[args.workload]), args.steps, args.warmup
     P = pb.n_params
 
     # synthetic draws: chain b of rank r in pool slot s owns mt19937(1 + (s*world + r)*B + b)
@@ -219,17 +225,17 @@ def main():
             try:
                 with open(traffic_src) as fh:
                     tj = json.load(fh)
-                key = f"{args.solver}_{args.arith}_B{B}"
+                key = f"{args.workload}_{solver_name}_{args.arith}_B{B}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "ODE-solve+likelihood evals/sec (SEPAIHRD 4-age, 400d)",
+            "metric": "ODE-solve+likelihood evals/sec (SEPAIHRD %d-age, %dd)" % (pb.n, int(pb.times[-1] - pb.times[0])),
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed_max / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: SEPAIHRD {pb.n} age groups, {args.solver}, "
+                "workload": f"BASELINE {args.workload}: SEPAIHRD {pb.n} age groups, {solver_name}, "
                             f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
                 "chains_per_gpu": B, "n_params": P, "abs_err": pb.abs_err, "rel_err": pb.rel_err,
                 "arith": args.arith, "other_arith": {"mode": other, "kernel_ms": other_ms,

@@ -278,3 +278,35 @@ def widen_age_classes(pb: SEPAIHRDProblem, factor: int) -> SEPAIHRDProblem:
                     initial_state=init, obs_H=spread(pb.obs_H), obs_ICU=spread(pb.obs_ICU),
                     obs_D=spread(pb.obs_D), param_names=names, sigmas=sig, bounds=bnd,
                     base_theta=np.array(base) if base else None)
+
+
+def restrict_age_classes(pb: SEPAIHRDProblem, keep: Sequence[int]) -> SEPAIHRDProblem:
+    """Sub-problem on a subset of age classes (test helper: n = 1, 2, 3 exercise the narrow and the
+    padded lane layouts).  Age-indexed parameter names are re-indexed; others are kept."""
+    keep = list(keep)
+    n = pb.n
+    sel = np.array(keep)
+    init = np.concatenate([pb.initial_state[c * n:(c + 1) * n][sel] for c in range(NUM_COMPARTMENTS)])
+    age_prefixes = sorted([p for p, _ in F_AGE_PREFIXES], key=len, reverse=True)
+    names, sig, bnd, base = [], {}, {}, []
+    for k, nm in enumerate(pb.param_names):
+        pref = next((p for p in age_prefixes if nm.startswith(p) and nm[len(p):].isdigit()), None)
+        if pref is not None:
+            i = int(nm[len(pref):])
+            if i not in keep:
+                continue
+            new = f"{pref}{keep.index(i)}"
+        else:
+            new = nm
+        names.append(new)
+        if nm in pb.sigmas:
+            sig[new] = pb.sigmas[nm]
+        if nm in pb.bounds:
+            bnd[new] = pb.bounds[nm]
+        if pb.base_theta is not None:
+            base.append(pb.base_theta[k])
+    return pb.with_(N=pb.N[sel], M=pb.M[np.ix_(sel, sel)], a=pb.a[sel], h_infec=pb.h_infec[sel], p=pb.p[sel],
+                    h=pb.h[sel], icu=pb.icu[sel], d_H=pb.d_H[sel], d_ICU=pb.d_ICU[sel],
+                    d_community=pb.d_community[sel], initial_state=init, obs_H=pb.obs_H[:, sel],
+                    obs_ICU=pb.obs_ICU[:, sel], obs_D=pb.obs_D[:, sel], param_names=names, sigmas=sig, bounds=bnd,
+                    base_theta=np.array(base) if base else None)

@@ -157,3 +157,27 @@ def test_full_size_properties(mm, synth400, draws):
     assert np.all(got["status"] == 0)
     assert np.all(ll == ll[0:1])
     assert np.all(got["n_accept"] >= 400)
+
+
+@pytest.mark.parametrize("n_age", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_other_age_class_counts(mm, oracle_py, shipped, n_age, solver):
+    """Lane layouts other than 4 lanes per chain: n = 1, 2 (narrow groups), n = 3 (padded to 4 lanes),
+    n = 8, 16 (wave-shuffle contraction; 16 is BASELINE config 5's shape)."""
+    from mmid_amd import draws
+    if n_age <= 3:
+        pb = mm.restrict_age_classes(shipped, list(range(n_age)))
+    else:
+        pb = mm.widen_age_classes(shipped, n_age // 4)
+    pb.solver = solver
+    pb.arith = mm.ARITH_STRICT
+    pb.times = pb.times[:120]
+    pb = pb.with_(obs_H=pb.obs_H[:100], obs_ICU=pb.obs_ICU[:100], obs_D=pb.obs_D[:100])
+    B = 19
+    theta = draws.jitter_draws(pb, 3, B)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"]) and np.all(ref["status"] == 0)
+    assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
