@@ -443,34 +443,36 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         oH = a.x; oI = a.y; oD = b.x; tn = b.y;
     };
 
-    auto observe = [&](int k, double oH, double oI, double oD) {
+    // Observer at output index k for the chains with do_it set (all lanes execute: the likelihood
+    // terms of the other chains are discarded, their lanes would idle anyway).  Records of outputs
+    // before t = 0 and of padded ages carry NaN observations, which the Poisson term skips.
+    auto observe = [&](bool do_it, int k, double oH, double oI, double oD) {
         double incH = x[9] - prevH, incICU = x[10] - prevICU, incD = x[8] - prevD;
         incH = (incH < 0.0) ? 0.0 : incH;  // cwiseMax(0.0)
         incICU = (incICU < 0.0) ? 0.0 : incICU;
         incD = (incD < 0.0) ? 0.0 : incD;
-        prevH = x[9]; prevICU = x[10]; prevD = x[8];
-        if (k >= pb.runup_offset) {
-            const double eps = 1e-10;
-            auto term = [&](double obs, double sim) -> double {
-                if (sim < 0.0) sim = 0.0;
-                sim += eps;
-                const double v = obs * log_pos(sim) - sim;
-                return (obs >= 0.0 && isfinite(obs)) ? v : 0.0;
-            };
-            const double tH = term(oH, incH), tI = term(oI, incICU), tD = term(oD, incD);
-            // row_sum over ages in ascending order (serial order of calculateSingleLogLikelihood)
-            auto row_sum = [&](double tv) -> double {
-                double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
-                [&]<int... J>(std::integer_sequence<int, J...>) {
-                    ((rs += group_bcast<LPC, J + 1>(tv)), ...);
-                }(std::make_integer_sequence<int, LPC - 1>{});
-                return rs;
-            };
-            llH += row_sum(tH);
-            llICU += row_sum(tI);
-            llD += row_sum(tD);
-        }
-        if (out.traj != nullptr && chain_valid && age < n_real) {
+        prevH = do_it ? x[9] : prevH;
+        prevICU = do_it ? x[10] : prevICU;
+        prevD = do_it ? x[8] : prevD;
+        const double eps = 1e-10;
+        auto term = [&](double obs, double sim) -> double {
+            sim += eps;  // sim >= 0 already
+            const double v = obs * log_pos(sim) - sim;
+            return (do_it && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
+        };
+        const double tH = term(oH, incH), tI = term(oI, incICU), tD = term(oD, incD);
+        // row_sum over ages in ascending order (serial order of calculateSingleLogLikelihood)
+        auto row_sum = [&](double tv) -> double {
+            double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                ((rs += group_bcast<LPC, J + 1>(tv)), ...);
+            }(std::make_integer_sequence<int, LPC - 1>{});
+            return rs;
+        };
+        llH += row_sum(tH);
+        llICU += row_sum(tI);
+        llD += row_sum(tD);
+        if (out.traj != nullptr && do_it && chain_valid && age < n_real) {
             double* dst = out.traj + ((size_t)chain * T + k) * (NUM_COMP * n_real) + age;
             SEP_UNROLL
             for (int c = 0; c < NUM_COMP; ++c) dst[c * n_real] = x[c];
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         const double* r0 = grid_lane;  // record 0 is read directly
         const double oH = r0[0], oI = r0[1], oD = r0[2];
         t_next = r0[3];
-        if (active) observe(0, oH, oI, oD);
+        observe(active, 0, oH, oI, oD);
     }
     if (T <= 1) active = false;
     // software prefetch: the record of the next output (its observations and the time after it) is
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
 #ifdef SEPAIHRD_STAMPS
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
     unsigned long long acc_head = 0, acc_body = 0, acc_err = 0, acc_tail = 0;
+    unsigned long long st5 = 0, st6 = 0, acc_errA = 0, acc_tailA = 0;
 #endif
     while (__ballot(active) != 0ull) {
         SEP_STAMP(st0);
@@ -642,32 +645,36 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
             err = group_max<LPC>(err);
         }
 
+        SEP_STAMP(st5);
         const bool reject = err > 1.0;
         ++attempts;
-        // default_step_adjuster: powers are only evaluated where some lane needs them
+        // default_step_adjuster.  decrease: dt *= max(0.9 err^(-1/3), 0.2); increase (err < 0.5):
+        // dt *= 0.9 max(5^-5, err)^(-1/5).  One exp(c log x) serves both directions; it is evaluated only
+        // when some lane needs it, and growth only matters while dt is below the largest output gap
+        // (dt = max(dt, grown) cannot change min(dt, gap) otherwise).
         const bool need_dec = active && reject;
-        // growth can only matter while dt is below the largest output gap (dt = max(dt, grown))
         const bool need_inc = active && !reject && (err < 0.5) && (dt < pb.max_gap);
         double cur_after = cur;
-        if (__ballot(need_dec) != 0ull) {
-            const double f = fmax(9.0 / 10.0 * pow_ctl(err, -1.0 / (4 - 1)), 1.0 / 5.0);
-            if (need_dec) cur_after = cur * f;
-        }
-        if (__ballot(need_inc) != 0ull) {
-            const double e2 = fmax(1.0 / 3125.0, err);  // std::pow(5.0, -5.0) == 1/3125 exactly rounded
-            const double f = 9.0 / 10.0 * pow_ctl(e2, -1.0 / 5);
-            if (need_inc) cur_after = cur * f;
+        if (__ballot(need_dec || need_inc) != 0ull) {
+            const double arg = need_dec ? err : fmax(1.0 / 3125.0, err);  // std::pow(5.0, -5.0) == 1/3125
+            const double expo = need_dec ? -1.0 / (4 - 1) : -1.0 / 5;
+            const double pw = 9.0 / 10.0 * pow_ctl(arg, expo);
+            const double f = need_dec ? fmax(pw, 1.0 / 5.0) : pw;
+            if (need_dec || need_inc) cur_after = cur * f;
         }
 
         SEP_STAMP(st3);
-        if (active) {
-            if (reject) {
-                ++n_rej;
-                dt = cur_after;  // dt = current_dt (reduced)
-                if (fails++ >= 500) { status = 2; active = false; }
-            } else {
-                ++n_acc;
-                fails = 0;
+        {
+            const bool rej = active && reject;
+            const bool acc = active && !reject;
+            n_rej += rej ? 1 : 0;
+            n_acc += acc ? 1 : 0;
+            // failure: dt = reduced current_dt; success: dt = max_abs(dt, current_dt)
+            dt = rej ? cur_after : (acc ? fmax(dt, cur_after) : dt);
+            // failed_step_checker: throws when 500 consecutive failures precede this one
+            if (rej && fails >= 500) { status = 2; active = false; }
+            fails = acc ? 0 : fails + (rej ? 1 : 0);
+            if (acc) {
                 t += cur;
                 SEP_UNROLL
                 for (int c = 0; c < NUM_COMP; ++c) x[c] = xnew[c];
@@ -675,13 +682,16 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
                     SEP_UNROLL
                     for (int c = 0; c < NUM_COMP; ++c) k1[c] = k7[c];
                 }
-                dt = fmax(dt, cur_after);  // max_abs(dt, current_dt)
-                // less_with_sign(t, t_next, dt): t_next - t > epsilon
-                if (!((t_next - t) > DBL_EPSILON)) {
+            }
+            SEP_STAMP(st6);
+            // less_with_sign(t, t_next, dt): t_next - t > epsilon
+            const bool reached = acc && !((t_next - t) > DBL_EPSILON);
+            if (__ballot(reached) != 0ull) {
+                double oH, oI, oD, tn;
+                read_record(oH, oI, oD, tn);
+                observe(reached, k_next, oH, oI, oD);
+                if (reached) {
                     t = t_next;  // integrate_times re-reads the exact grid time
-                    double oH, oI, oD, tn;
-                    read_record(oH, oI, oD, tn);
-                    observe(k_next, oH, oI, oD);
                     ++k_next;
                     t_next = tn;
                     if (k_next >= T) active = false;
@@ -693,6 +703,9 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         SEP_STAMP(st4);
 #ifdef SEPAIHRD_STAMPS
         acc_head += st1 - st0; acc_body += st2 - st1; acc_err += st3 - st2; acc_tail += st4 - st3;
+        acc_errA += st5 - st2;                       // scale/compare + division path (before the pow paths)
+        if (st6 > st3) acc_tailA += st6 - st3;       // reject/accept state update (before observe)
+        st6 = 0;
 #endif
     }
 
@@ -721,7 +734,10 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
         if (out.ll_parts && grp == 1) {
             out.ll_parts[3 * chain + 0] = (double)acc_tail;
             out.ll_parts[3 * chain + 1] = (double)attempts;
+            out.ll_parts[3 * chain + 2] = (double)acc_errA;
         }
+        if (out.ll_parts && grp == 2) out.ll_parts[3 * chain + 0] = (double)acc_tailA;
+
 #endif
     }
 }

@@ -17,10 +17,13 @@ hip.eval_batch(theta)
 r = hip.eval_batch(theta)
 parts = r["ll_parts"].reshape(-1, 16, 3)  # per wave: 16 chains
 head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
-tail, att = parts[:, 1, 0], parts[:, 1, 1]
+tail, att, errA = parts[:, 1, 0], parts[:, 1, 1], parts[:, 1, 2]
+tailA = parts[:, 2, 0]
 tot = head + body + err + tail
 print("arith", arith, "waves", len(tot), "attempts/wave mean %.1f" % att.mean())
 for name, v in (("head(stage times, schedule)", head), ("RK body (6 RHS + stage sums + xerr)", body),
                 ("error norm + controller", err), ("accept/observe/likelihood tail", tail)):
     print("%-40s %8.0f cycles/attempt  %5.1f %%" % (name, (v / att).mean(), 100 * v.sum() / tot.sum()))
+print("   of error section: scale/compare/divisions %.0f, controller pow paths %.0f" % ((errA / att).mean(), ((err - errA) / att).mean()))
+print("   of tail: reject/accept state update %.0f, observe+likelihood+prefetch %.0f" % ((tailA / att).mean(), ((tail - tailA) / att).mean()))
 print("total stamped cycles/attempt %.0f (s_memtime ticks)" % (tot / att).mean())
