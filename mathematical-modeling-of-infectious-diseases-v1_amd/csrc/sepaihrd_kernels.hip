@@ -246,11 +246,12 @@ __device__ __forceinline__ void segment_index2(const Schedule& s, int nm_pad, do
 
 // ----------------------------------------------------------------------------------
 // natural log for the Poisson term.  Argument reduction x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2),
-// s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the classic degree-14 minimax
-// R (error < 2^-58.45 on the reduced interval); < 1 ulp overall, ~45 instructions instead of the
-// device library's ~125.  Explicit fma() here is not contraction: the likelihood's log is a libm
-// call in the reference (std::log), never bit-pinned.  Non-positive / non-finite / subnormal
-// arguments take the device library path.
+// s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the classic degree-14 minimax R
+// (error < 2^-58.45 on the reduced interval); < 1 ulp overall in ~45 instructions, no branches, so
+// the three logs of one output day interleave instead of serialising three dependent chains.
+// Explicit fma() here is not contraction: the likelihood's log is a libm call in the reference
+// (std::log), never bit-pinned.  Domain: x >= 1e-10 by construction (sim + epsilon); +inf and NaN
+// pass through, which is all that can reach it from a blown-up state.
 // ----------------------------------------------------------------------------------
 __device__ __forceinline__ double log_pos(double x) {
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -258,8 +259,6 @@ __device__ __forceinline__ double log_pos(double x) {
                      Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                      Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                      Lg7 = 1.479819860511658591e-01;
-    const bool regular = (x >= 2.2250738585072014e-308) && (x < INFINITY);
-    if (__ballot(!regular) != 0ull) return log(x);  // wave-uniform: rare
     int k = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^k, m in [0.5, 1)
     double m = __builtin_amdgcn_frexp_mant(x);
     const bool low = m < 0.70710678118654752440;
@@ -267,14 +266,23 @@ __device__ __forceinline__ double log_pos(double x) {
     k = low ? k - 1 : k;
     const double f = m - 1.0;
     const double dk = (double)k;
-    const double sdiv = f / (2.0 + f);
+    // s = f / (2 + f): denominator in [1.70, 2.42], so a Newton-refined reciprocal and one residual
+    // correction give the correctly rounded quotient's neighbourhood (<= 1 ulp) without the IEEE
+    // division's scaling / fix-up instructions
+    const double den = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double sdiv = f * r;
+    sdiv = fma(fma(-den, sdiv, f), r, sdiv);
     const double z = sdiv * sdiv;
     const double w = z * z;
     const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
     const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
-    return dk * ln2_hi - ((hfsq - fma(sdiv, hfsq + R, dk * ln2_lo)) - f);
+    const double res = dk * ln2_hi - ((hfsq - fma(sdiv, hfsq + R, dk * ln2_lo)) - f);
+    return (x < INFINITY) ? res : x;                // +inf -> +inf, NaN -> NaN
 }
 
 // exp for the step-size controller: p = k ln2 + r, |r| <= ln2/2, degree-13 Taylor (remainder < 5e-18).
