@@ -68,7 +68,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SEPAIHRD_HIP_LIB") or LIB_PATH  # env override: experiment builds only
     # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
     # libhsa-runtime64 and a second copy (the system ROCm the library was linked against) cannot
     # open the device once the first has.  Importing torch FIRST makes the dynamic linker resolve
