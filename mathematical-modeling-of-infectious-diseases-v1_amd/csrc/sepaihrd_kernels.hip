@@ -139,11 +139,13 @@ constexpr double db1 = 37.0 / 378 - 2825.0 / 27648, db3 = 250.0 / 621 - 18575.0 
 // ----------------------------------------------------------------------------------
 // per-lane model record
 // ----------------------------------------------------------------------------------
+enum ModelField { MF_THETA = 0, MF_SIGMA, MF_GAMMA_P, MF_GAMMA_A, MF_GAMMA_I, MF_GAMMA_H, MF_GAMMA_ICU, MF_A,
+                  MF_H_INFEC, MF_P, MF_H, MF_ICU, MF_D_H, MF_D_ICU, MF_D_COMM, MF_INV_N, MF_MROW0 };
 template <int LPC>
-struct LaneModel {
-    double theta, sigma, gamma_p, gamma_A, gamma_I, gamma_H, gamma_ICU;
-    double a, h_infec, p, h, icu, d_H, d_ICU, d_comm, inv_N;
-    double Mrow[LPC];
+struct LaneModel {  // VGPR-resident (an LDS-resident variant measured no gain at 1 wave/SIMD and lost at 2)
+    double v[MF_MROW0 + LPC];
+    __device__ __forceinline__ double get(int f) const { return v[f]; }
+    __device__ __forceinline__ void set(int f, double val) { v[f] = val; }
 };
 
 // AgeSEPAIHRDModel::computeDerivatives for this lane's age class.
@@ -152,39 +154,39 @@ template <int LPC>
 __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[NUM_COMP],
                                     double (&dx)[NUM_COMP], double beta_eff) {
     const double S = x[0], E = x[1], P = x[2], A = x[3], I = x[4], H = x[5], ICU = x[6];
-    const double total_inf = P + A + q.theta * I;
-    const double inf_pressure = total_inf * q.h_infec * q.inv_N;
+    const double total_inf = P + A + q.get(MF_THETA) * I;
+    const double inf_pressure = total_inf * q.get(MF_H_INFEC) * q.get(MF_INV_N);
     // lambda_i = 0.0 + M(i,0) pi_0 + M(i,1) pi_1 + ..., j ascending (column-major walk of the reference).
     // The leading "0.0 +" only turns a -0.0 first product into +0.0, which max(0.0, .) below does anyway.
-    double lambda = q.Mrow[0] * group_bcast<LPC, 0>(inf_pressure);
+    double lambda = q.get(MF_MROW0) * group_bcast<LPC, 0>(inf_pressure);
     [&]<int... J>(std::integer_sequence<int, J...>) {
-        ((lambda += q.Mrow[J + 1] * group_bcast<LPC, J + 1>(inf_pressure)), ...);
+        ((lambda += q.get(MF_MROW0 + J + 1) * group_bcast<LPC, J + 1>(inf_pressure)), ...);
     }(std::make_integer_sequence<int, LPC - 1>{});
-    lambda *= beta_eff * q.a;
+    lambda *= beta_eff * q.get(MF_A);
     const double lambda_val = (0.0 < lambda) ? lambda : 0.0;  // std::max(0.0, lambda)
 
     const double flow_SE = lambda_val * S;
-    const double flow_EP = q.sigma * E;
-    const double flow_P_out = q.gamma_p * P;
-    const double flow_PA = q.p * flow_P_out;
+    const double flow_EP = q.get(MF_SIGMA) * E;
+    const double flow_P_out = q.get(MF_GAMMA_P) * P;
+    const double flow_PA = q.get(MF_P) * flow_P_out;
     const double flow_PI = flow_P_out - flow_PA;
-    const double flow_IH = q.h * I;
-    const double flow_IR = q.gamma_I * I;
-    const double flow_ID_community = q.d_comm * I;
+    const double flow_IH = q.get(MF_H) * I;
+    const double flow_IR = q.get(MF_GAMMA_I) * I;
+    const double flow_ID_community = q.get(MF_D_COMM) * I;
     const double I_out = flow_IR + flow_IH + flow_ID_community;
-    const double flow_H_ICU = q.icu * H;
-    const double H_out = q.gamma_H * H + q.d_H * H + flow_H_ICU;
-    const double ICU_out = (q.gamma_ICU + q.d_ICU) * ICU;
+    const double flow_H_ICU = q.get(MF_ICU) * H;
+    const double H_out = q.get(MF_GAMMA_H) * H + q.get(MF_D_H) * H + flow_H_ICU;
+    const double ICU_out = (q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU)) * ICU;
 
     dx[0] = -flow_SE;
     dx[1] = flow_SE - flow_EP;
     dx[2] = flow_EP - flow_P_out;
-    dx[3] = flow_PA - q.gamma_A * A;
+    dx[3] = flow_PA - q.get(MF_GAMMA_A) * A;
     dx[4] = flow_PI - I_out;
     dx[5] = flow_IH - H_out;
     dx[6] = flow_H_ICU - ICU_out;
-    dx[7] = q.gamma_A * A + flow_IR + q.gamma_H * H + q.gamma_ICU * ICU;
-    dx[8] = q.d_H * H + q.d_ICU * ICU + flow_ID_community;
+    dx[7] = q.get(MF_GAMMA_A) * A + flow_IR + q.get(MF_GAMMA_H) * H + q.get(MF_GAMMA_ICU) * ICU;
+    dx[8] = q.get(MF_D_H) * H + q.get(MF_D_ICU) * ICU + flow_ID_community;
     dx[9] = flow_IH;
     dx[10] = flow_H_ICU;
 }
@@ -315,8 +317,12 @@ __device__ __forceinline__ double pow_ctl(double x, double c) { return exp_ctl(c
 // ----------------------------------------------------------------------------------
 // the evaluation kernel: block = one wavefront = 64/LPC chains
 // ----------------------------------------------------------------------------------
-template <int LPC, int SOLVER, int ARITH_FMA>
-__global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb,
+// WPS = waves per SIMD the register allocation is budgeted for.  1 (up to 512 unified VGPRs) is the
+// default; the Cash-Karp stepper (no FSAL derivative, fewer live stage vectors) also gets a 2-wave
+// build, launched when the batch is large enough to put two waves on every SIMD: measured +13..22 %
+// there, while the Dopri5 body loses at 2 waves/SIMD (its spills go to scratch).
+template <int LPC, int SOLVER, int ARITH_FMA, int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProblem pb,
                                                               const double* __restrict__ theta,
                                                               const int B, const EvalOutputs out) {
     constexpr int CPW = WAVE / LPC;
@@ -362,25 +368,25 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
 
     // ---- 2. theta -> model (updateModelParameters + setModelParameters)
     LaneModel<LPC> q;
-    q.theta = scalar_slot(SS_THETA);
-    q.sigma = scalar_slot(SS_SIGMA);
-    q.gamma_p = scalar_slot(SS_GAMMA_P);
-    q.gamma_A = scalar_slot(SS_GAMMA_A);
-    q.gamma_I = scalar_slot(SS_GAMMA_I);
-    q.gamma_H = scalar_slot(SS_GAMMA_H);
-    q.gamma_ICU = scalar_slot(SS_GAMMA_ICU);
-    q.a = vec_slot(VF_A);
-    q.h_infec = vec_slot(VF_H_INFEC);
-    q.p = vec_slot(VF_P);
-    q.h = vec_slot(VF_H);
-    q.icu = vec_slot(VF_ICU);
-    q.d_H = vec_slot(VF_D_H);
-    q.d_ICU = vec_slot(VF_D_ICU);
-    q.d_comm = vec_slot(VF_D_COMM);
+    q.set(MF_THETA, scalar_slot(SS_THETA));
+    q.set(MF_SIGMA, scalar_slot(SS_SIGMA));
+    q.set(MF_GAMMA_P, scalar_slot(SS_GAMMA_P));
+    q.set(MF_GAMMA_A, scalar_slot(SS_GAMMA_A));
+    q.set(MF_GAMMA_I, scalar_slot(SS_GAMMA_I));
+    q.set(MF_GAMMA_H, scalar_slot(SS_GAMMA_H));
+    q.set(MF_GAMMA_ICU, scalar_slot(SS_GAMMA_ICU));
+    q.set(MF_A, vec_slot(VF_A));
+    q.set(MF_H_INFEC, vec_slot(VF_H_INFEC));
+    q.set(MF_P, vec_slot(VF_P));
+    q.set(MF_H, vec_slot(VF_H));
+    q.set(MF_ICU, vec_slot(VF_ICU));
+    q.set(MF_D_H, vec_slot(VF_D_H));
+    q.set(MF_D_ICU, vec_slot(VF_D_ICU));
+    q.set(MF_D_COMM, vec_slot(VF_D_COMM));
     const double Ni = pb.N[age];
-    q.inv_N = (Ni > 1e-9) ? (1.0 / Ni) : 0.0;  // AgeSEPAIHRDModel.cpp:332-334
+    q.set(MF_INV_N, (Ni > 1e-9) ? (1.0 / Ni) : 0.0);  // AgeSEPAIHRDModel.cpp:332-334
     SEP_UNROLL
-    for (int j = 0; j < LPC; ++j) q.Mrow[j] = pb.Mrow[age * LPC + j];
+    for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, pb.Mrow[age * LPC + j]);
 
     // beta(t) kappa(t) on every merged segment: "current_beta * reduction_factor" of the RHS, once per chain
     Schedule sch;
@@ -753,21 +759,31 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_eval_kernel(const DevProblem pb
 // ----------------------------------------------------------------------------------
 // launch plumbing
 // ----------------------------------------------------------------------------------
-template <int LPC, int SOLVER>
-int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOutputs& out, void* stream) {
-    constexpr int CPW = WAVE / LPC;
-    const int blocks = (B + CPW - 1) / CPW;
-    if (blocks <= 0) return 0;
+template <int LPC, int SOLVER, int WPS>
+int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, const EvalOutputs& out, void* stream) {
     const size_t lds = eval_lds_bytes(pb);
-    hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA>), dim3(blocks), dim3(WAVE), lds,
+    hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>), dim3(blocks), dim3(WAVE), lds,
                        static_cast<hipStream_t>(stream), pb, d_theta, B, out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int LPC, int SOLVER>
+int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOutputs& out, void* stream) {
+    constexpr int CPW = WAVE / LPC;
+    const int blocks = (B + CPW - 1) / CPW;
+    if (blocks <= 0) return 0;
+    if constexpr (SOLVER == 1) {
+        // two waves per SIMD only pay when there are two waves for every SIMD (256 CUs x 4 SIMDs)
+        if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2>(pb, d_theta, blocks, B, out, stream);
+    }
+    return launch_wps<LPC, SOLVER, 1>(pb, d_theta, blocks, B, out, stream);
+}
+
+template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, LaunchInfo* info, const char* name) {
+    constexpr int WPS = 1;
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA>)) !=
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>)) !=
         hipSuccess)
         return -3;
     info->vgprs = attr.numRegs;
@@ -775,7 +791,7 @@ int info_one(const DevProblem& pb, LaunchInfo* info, const char* name) {
     info->lds_static = (int)attr.sharedSizeBytes;
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA>, WAVE,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>, WAVE,
                                                      eval_lds_bytes(pb)) != hipSuccess)
         nb = -1;
     info->max_blocks_per_cu = nb;
