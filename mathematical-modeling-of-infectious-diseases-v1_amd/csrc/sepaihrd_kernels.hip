@@ -76,8 +76,9 @@ __device__ __forceinline__ double group_bcast(double v) {
     }
 }
 
-// NaN-ignoring max (std::max(init, v) with init never NaN: odeint's norm_inf)
-__device__ __forceinline__ double max_keep(double m, double v) { return (m < v) ? v : m; }
+// NaN-ignoring max (std::max(init, v) with init never NaN: odeint's norm_inf).  fmax = v_max_f64 returns
+// the non-NaN operand, which is exactly (m < v) ? v : m for a non-NaN m -- one instruction instead of three.
+__device__ __forceinline__ double max_keep(double m, double v) { return fmax(m, v); }
 
 template <int LPC>
 __device__ __forceinline__ double group_max(double m) {
