@@ -177,11 +177,17 @@ int sepaihrd_eval_batch(sepaihrd_ctx *ctx, const double *theta, int B, double *l
                         double *traj);
 
 /* Device-pointer form: same arguments but every pointer is a DEVICE pointer on ctx's device,
- * and the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * No allocation, no synchronisation: safe inside stream capture. */
+ * and the launches (integrator kernel + two likelihood-pass kernels) are asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream).  No synchronisation.  The ctx-owned workspace
+ * (D, CumH, CumICU of every chain at every output: T*3*n*8 bytes per chain) grows on the first call
+ * for a larger batch; call sepaihrd_reserve first when the call must not allocate (stream capture).
+ * Batches whose workspace would exceed 24 GiB are evaluated in chunks of chains on the same stream. */
 int sepaihrd_eval_batch_device(sepaihrd_ctx *ctx, const double *d_theta, int B, double *d_loglik,
                                int32_t *d_status, int32_t *d_n_accept, int32_t *d_n_reject,
                                double *d_ll_parts, double *d_traj, void *stream);
+
+/* Pre-allocate the workspace for batches of up to max_B chains. */
+int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
 
 /* applyConstraints for B vectors on the host (exactly the device's arithmetic). */
 int sepaihrd_apply_constraints(const sepaihrd_ctx *ctx, int mode, const double *in, int B, double *out);

@@ -40,6 +40,12 @@ struct sepaihrd_ctx {
     double* d_parts = nullptr;
     double* d_traj = nullptr;
     size_t cap_traj_elems = 0;
+    // likelihood-pass workspace (device), sized for ws_chains chains
+    size_t ws_chains = 0;
+    double* ws_cum = nullptr;
+    double* ws_rows = nullptr;
+    int32_t* ws_status = nullptr;
+    size_t ws_budget_bytes = (size_t)24 << 30;  // larger batches are evaluated in chunks of chains
 };
 
 namespace {
@@ -83,6 +89,38 @@ double reflect_bound_host(double value, double minb, double maxb) {
     return maxb - (y - width);
 }
 
+void free_workspace(sepaihrd_ctx* c) {
+    if (c->ws_cum) (void)hipFree(c->ws_cum);
+    if (c->ws_rows) (void)hipFree(c->ws_rows);
+    if (c->ws_status) (void)hipFree(c->ws_status);
+    c->ws_cum = c->ws_rows = nullptr;
+    c->ws_status = nullptr;
+    c->ws_chains = 0;
+}
+
+// chains per launch so that the cumulative-compartment workspace stays within the budget
+size_t chunk_chains(const sepaihrd_ctx* c, size_t B) {
+    const size_t cpw = (size_t)(WAVE / c->dp.lpc);
+    const size_t per_chain = (size_t)c->dp.T * 3 * c->dp.lpc * sizeof(double);
+    size_t fit = std::max<size_t>(cpw, (c->ws_budget_bytes / per_chain) / cpw * cpw);
+    const size_t want = (B + cpw - 1) / cpw * cpw;
+    return std::min(fit, want);
+}
+
+int ensure_workspace(sepaihrd_ctx* c, size_t chains) {
+    if (chains <= c->ws_chains) return SEPAIHRD_OK;
+    free_workspace(c);
+    if (hipMalloc((void**)&c->ws_cum, workspace_cum_doubles(c->dp, chains) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->ws_rows, workspace_rows_doubles(c->dp, chains) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->ws_status, chains * sizeof(int32_t)) != hipSuccess) {
+        free_workspace(c);
+        c->last_error = "likelihood workspace allocation failed";
+        return SEPAIHRD_E_HIP;
+    }
+    c->ws_chains = chains;
+    return SEPAIHRD_OK;
+}
+
 void free_staging(sepaihrd_ctx* c) {
     void* ptrs[] = {c->d_theta, c->d_loglik, c->d_status, c->d_nacc, c->d_nrej, c->d_parts, c->d_traj};
     for (void* p : ptrs)
@@ -108,6 +146,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
         set_err(err, errlen, "n_age > 16 not built in this version"); return nullptr;
     }
     if (T < 1) { set_err(err, errlen, "n_times must be >= 1"); return nullptr; }
+    if (T > MAX_TIMES) { set_err(err, errlen, "n_times exceeds the LDS-staged grid limit (12288)"); return nullptr; }
     if (P < 1) { set_err(err, errlen, "n_params must be >= 1"); return nullptr; }
     if (nk < 1 || nk > SEPAIHRD_MAX_SCHEDULE || nb < 0 || nb > SEPAIHRD_MAX_SCHEDULE) {
         set_err(err, errlen, "schedule lengths out of range (n_kappa >= 1)"); return nullptr;
@@ -317,6 +356,7 @@ void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_staging(ctx);
+    free_workspace(ctx);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
 }
@@ -336,6 +376,12 @@ int sepaihrd_set_arith(sepaihrd_ctx* ctx, int arith) {
     return SEPAIHRD_OK;
 }
 
+int sepaihrd_reserve(sepaihrd_ctx* ctx, int max_B) {
+    if (!ctx || max_B < 0) return SEPAIHRD_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    return ensure_workspace(ctx, chunk_chains(ctx, (size_t)max_B));
+}
+
 int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, double* d_loglik,
                                int32_t* d_status, int32_t* d_n_accept, int32_t* d_n_reject,
                                double* d_ll_parts, double* d_traj, void* stream) {
@@ -345,13 +391,34 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
         return SEPAIHRD_E_INVALID_ARG;
     }
     if (B == 0) return SEPAIHRD_OK;
-    EvalOutputs out{d_loglik, d_status, d_n_accept, d_n_reject, d_ll_parts, d_traj};
-    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA
-                       ? launch_eval_fma(ctx->dp, ctx->solver, d_theta, B, out, stream)
-                       : launch_eval_strict(ctx->dp, ctx->solver, d_theta, B, out, stream);
-    if (rc != 0) {
-        ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
-        return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
+    // The workspace grows on the first call for a larger batch (an allocation: call sepaihrd_reserve
+    // beforehand when the launch must be allocation-free, e.g. under stream capture).
+    const size_t cpw = (size_t)(WAVE / ctx->dp.lpc);
+    const size_t waves = ((size_t)B + cpw - 1) / cpw;
+    // batches that fill the chip use the inline-likelihood kernel and need no workspace / chunking
+    const bool split = waves <= (size_t)SPLIT_LL_MAX_BLOCKS;
+    const size_t chunk = split ? chunk_chains(ctx, (size_t)B) : (size_t)B;
+    if (split) {
+        const int rc = ensure_workspace(ctx, chunk);
+        if (rc != SEPAIHRD_OK) return rc;
+    }
+    const size_t traj_per_chain = (size_t)ctx->T * NUM_COMP * ctx->n;
+    for (size_t off = 0; off < (size_t)B; off += chunk) {
+        const int nb = (int)std::min(chunk, (size_t)B - off);
+        EvalOutputs out{d_loglik + off,
+                        d_status ? d_status + off : nullptr,
+                        d_n_accept ? d_n_accept + off : nullptr,
+                        d_n_reject ? d_n_reject + off : nullptr,
+                        d_ll_parts ? d_ll_parts + 3 * off : nullptr,
+                        d_traj ? d_traj + off * traj_per_chain : nullptr,
+                        ctx->ws_cum, ctx->ws_rows, ctx->ws_status};
+        const double* th = d_theta + off * (size_t)ctx->P;
+        const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
+                                                         : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
+        if (rc != 0) {
+            ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
+            return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
+        }
     }
     return SEPAIHRD_OK;
 }

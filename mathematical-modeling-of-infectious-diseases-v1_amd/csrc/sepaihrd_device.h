@@ -59,7 +59,16 @@ struct EvalOutputs {
     int32_t* n_reject;  // [B] or null
     double* ll_parts;   // [B][3] or null
     double* traj;       // [B][T][11][n] or null
+    // workspace of the likelihood pass (ctx-owned):
+    //   cum  [T][3][Bc*lpc]  daily increments of D, CumH, CumICU of every lane (coalesced rows)
+    //   rows [T][3][Bc]      per-day row sums of the three streams
+    //   wstatus [Bc]         integrator status per chain (always written, `status` may be null)
+    double* cum;
+    double* rows;
+    int32_t* wstatus;
 };
+inline size_t workspace_cum_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains * pb.lpc; }
+inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains; }
 
 struct LaunchInfo {
     int vgprs, sgprs, lds_static, scratch, max_blocks_per_cu;
@@ -80,14 +89,24 @@ inline int lanes_per_chain(int n) {
     return l;
 }
 // LDS carve (one wavefront per block), in doubles:
-//   [0, 256)                      grid-record landing zone: 2 x (64 lanes x 16 B), LDS-DMA destination
-//   [256, 256 + nm_pad)           merged period end times (+inf padded to an even count)
+//   [0, T_pad)                    output times (T rounded up to even)
+//   [.., + 256)                   observation-record landing zone (inline-likelihood build)
+//   [.., + nm_pad)                merged period end times (+inf padded to an even count)
 //   [.., + cpw*(nm+1))            per-chain beta*kappa of every merged segment
 //   [.., + cpw*P)                 constrained theta of the wave's chains (prologue only)
-constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;
+constexpr int MAX_TIMES = 12288;  // output grid staged in LDS (96 KiB at the cap)
+constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;  // LDS-DMA landing zone of the inline-likelihood build
+constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is used
+#if defined(__HIPCC__)
+#define SEP_HOST_DEVICE __host__ __device__
+#else
+#define SEP_HOST_DEVICE
+#endif
+SEP_HOST_DEVICE inline int times_pad(const DevProblem& pb) { return (pb.T + 1) & ~1; }
 inline size_t eval_lds_bytes(const DevProblem& pb) {
     const int cpw = WAVE / pb.lpc;
-    return ((size_t)LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P) * sizeof(double);
+    return ((size_t)times_pad(pb) + LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P) *
+           sizeof(double);
 }
 
 }  // namespace sepaihrd

@@ -337,14 +337,22 @@ __device__ __forceinline__ double pow_ctl(double x, double c) { return exp_ctl(c
 // default; the Cash-Karp stepper (no FSAL derivative, fewer live stage vectors) also gets a 2-wave
 // build, launched when the batch is large enough to put two waves on every SIMD: measured +13..22 %
 // there, while the Dopri5 body loses at 2 waves/SIMD (its spills go to scratch).
-template <int LPC, int SOLVER, int ARITH_FMA, int WPS>
+// INLINE_LL selects where the Poisson terms are evaluated:
+//   false  the integrator parks the daily increments of D, CumH, CumICU in HBM and a separate pass,
+//          parallel over (chain, day, age), evaluates the likelihood -- best while the batch does not
+//          fill the chip (4096 chains: 1.24 -> 1.09 ms per step);
+//   true   three logs per output inside the wave, observation records prefetched by LDS-DMA -- best
+//          at saturation, where the separate pass would add HBM traffic to the same VALU work.
+template <int LPC, int SOLVER, int ARITH_FMA, int WPS, bool INLINE_LL>
 __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProblem pb,
                                                               const double* __restrict__ theta,
-                                                              const int B, const EvalOutputs out) {
+                                                              const int B, const EvalOutputs out,
+                                                              const int cum_chains) {
     constexpr int CPW = WAVE / LPC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* const lds_rec = lds;                       // [2][64 lanes][2]  LDS-DMA landing zone
-    double* const lds_mends = lds + LDS_REC_DOUBLES;   // [nm_pad]
+    double* const lds_times = lds;                     // [T] output grid
+    double* const lds_rec = lds + times_pad(pb);       // [2][64 lanes][2]  LDS-DMA landing zone (INLINE_LL)
+    double* const lds_mends = lds_rec + LDS_REC_DOUBLES;  // [nm_pad]
     double* const lds_bk = lds_mends + pb.nm_pad;      // [CPW][nm + 1]
     double* const lds_theta = lds_bk + CPW * (pb.nm + 1);
     const int lane = threadIdx.x;
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         }
     }
     for (int k = lane; k < pb.nm_pad; k += WAVE) lds_mends[k] = pb.mends[k];
+    for (int k = lane; k < pb.T; k += WAVE) lds_times[k] = pb.times[k];
     __syncthreads();
     const double* th = lds_theta + g * P;
 
@@ -448,16 +457,19 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         x[0] = Ni - sum;
     }
 
-    // incidence bookkeeping: previous observed values of D, CumH, CumICU (row 0 vs init_state)
-    double prevD = x[8], prevH = x[9], prevICU = x[10];
-    double llH = 0.0, llICU = 0.0, llD = 0.0;
     int n_acc = 0, n_rej = 0;
     const int T = pb.T;
     const int n_real = pb.n;
 
-    // grid record of output index k for this lane: {obs_H, obs_ICU, obs_D, times[k+1]}.
-    // request_record() is an LDS-DMA (global_load_lds_dwordx4 x2): no VGPR destination, nothing to
-    // wait for until the record is read one whole RK step later.
+    // Observer at output index k for the chains with do_it set.  The likelihood only needs the daily
+    // increments of D, CumH, CumICU and never feeds back into the dynamics.
+    const size_t cum_stride = (size_t)cum_chains * LPC;
+    double* const cum_lane = out.cum + (size_t)(chain0 + grp) * LPC + age;  // own column, shadow groups too
+    double prevD = x[8], prevH = x[9], prevICU = x[10];  // row 0: X(0) - init_state = 0
+    double llH = 0.0, llICU = 0.0, llD = 0.0;             // INLINE_LL accumulators
+
+    // INLINE_LL: grid record of output k for this lane, {obs_H, obs_ICU, obs_D, times[k+1]}, requested by
+    // LDS-DMA (global_load_lds_dwordx4 x2: no VGPR destination) one whole RK step before it is read.
     const double* grid_lane = pb.grid + (size_t)age * 4;
     auto request_record = [&](int k) {
         const double* src = grid_lane + (size_t)k * (LPC * 4);
@@ -466,17 +478,28 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2),
                                          (__attribute__((address_space(3))) void*)(lds_rec + 2 * WAVE), 16, 0, 0);
     };
-    auto read_record = [&](double& oH, double& oI, double& oD, double& tn) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const double2 a = *reinterpret_cast<const double2*>(lds_rec + 2 * lane);
-        const double2 b = *reinterpret_cast<const double2*>(lds_rec + 2 * WAVE + 2 * lane);
-        oH = a.x; oI = a.y; oD = b.x; tn = b.y;
-    };
 
-    // Observer at output index k for the chains with do_it set (all lanes execute: the likelihood
-    // terms of the other chains are discarded, their lanes would idle anyway).  Records of outputs
-    // before t = 0 and of padded ages carry NaN observations, which the Poisson term skips.
-    auto observe = [&](bool do_it, int k, double oH, double oI, double oD) {
+    auto store_traj = [&](int k) {
+        if (out.traj != nullptr && chain_valid && age < n_real) {
+            double* tdst = out.traj + ((size_t)chain * T + k) * (NUM_COMP * n_real) + age;
+            SEP_UNROLL
+            for (int c = 0; c < NUM_COMP; ++c) tdst[c * n_real] = x[c];
+        }
+    };
+    // split form: park the raw increments (one coalesced 512-B store per wave and compartment)
+    auto observe_store = [&](bool do_it, int k) {
+        if (do_it) {
+            double* dst = cum_lane + (size_t)k * 3 * cum_stride;
+            dst[0] = x[8] - prevD;
+            dst[cum_stride] = x[9] - prevH;
+            dst[2 * cum_stride] = x[10] - prevICU;
+            prevD = x[8]; prevH = x[9]; prevICU = x[10];
+            store_traj(k);
+        }
+    };
+    // inline form: all lanes execute, the terms of chains without do_it are discarded.  Records of
+    // outputs before t = 0 and of padded ages carry NaN observations, which the Poisson term skips.
+    auto observe_inline = [&](bool do_it, int k, double oH, double oI, double oD) {
         double incH = x[9] - prevH, incICU = x[10] - prevICU, incD = x[8] - prevD;
         incH = (incH < 0.0) ? 0.0 : incH;  // cwiseMax(0.0)
         incICU = (incICU < 0.0) ? 0.0 : incICU;
@@ -484,15 +507,13 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         prevH = do_it ? x[9] : prevH;
         prevICU = do_it ? x[10] : prevICU;
         prevD = do_it ? x[8] : prevD;
-        const double eps = 1e-10;
         auto term = [&](double obs, double sim) -> double {
-            sim += eps;  // sim >= 0 already
+            sim += 1e-10;
             const double v = obs * log_pos(sim) - sim;
             return (do_it && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
         };
         const double tH = term(oH, incH), tI = term(oI, incICU), tD = term(oD, incD);
-        // row_sum over ages in ascending order (serial order of calculateSingleLogLikelihood)
-        auto row_sum = [&](double tv) -> double {
+        auto row_sum = [&](double tv) -> double {  // ages ascending: calculateSingleLogLikelihood's inner loop
             double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 ((rs += group_bcast<LPC, J + 1>(tv)), ...);
@@ -502,11 +523,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         llH += row_sum(tH);
         llICU += row_sum(tI);
         llD += row_sum(tD);
-        if (out.traj != nullptr && do_it && chain_valid && age < n_real) {
-            double* dst = out.traj + ((size_t)chain * T + k) * (NUM_COMP * n_real) + age;
-            SEP_UNROLL
-            for (int c = 0; c < NUM_COMP; ++c) dst[c * n_real] = x[c];
-        }
+        if (do_it) store_traj(k);
     };
 
     // ---- 4. integrate_times(controlled stepper, ..., times, dt_hint, observer)
@@ -517,16 +534,15 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     double dt = pb.dt_hint;
     int fails = 0;
     int attempts = 0;
-    {
-        const double* r0 = grid_lane;  // record 0 is read directly
-        const double oH = r0[0], oI = r0[1], oD = r0[2];
-        t_next = r0[3];
-        observe(active, 0, oH, oI, oD);
+    t_next = (T > 1) ? pb.times[1] : t;
+    if constexpr (INLINE_LL) {
+        const double oH = grid_lane[0], oI = grid_lane[1], oD = grid_lane[2];  // record 0 is read directly
+        observe_inline(active, 0, oH, oI, oD);
+        if (active && T > 1) request_record(1);
+    } else {
+        observe_store(active && chain_valid, 0);
     }
     if (T <= 1) active = false;
-    // software prefetch: the record of the next output (its observations and the time after it) is
-    // requested one whole RK step before it is needed, so no step waits on HBM/L2 latency
-    if (active) request_record(1);
 
     sch.lo = INFINITY; sch.hi = -INFINITY; sch.bk = 0.0;  // empty segment: first step refreshes
     double k1[NUM_COMP];
@@ -719,17 +735,26 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
             SEP_STAMP(st6);
             // less_with_sign(t, t_next, dt): t_next - t > epsilon
             const bool reached = acc && !((t_next - t) > DBL_EPSILON);
-            if (__ballot(reached) != 0ull) {
-                double oH, oI, oD, tn;
-                read_record(oH, oI, oD, tn);
-                observe(reached, k_next, oH, oI, oD);
-                if (reached) {
-                    t = t_next;  // integrate_times re-reads the exact grid time
-                    ++k_next;
-                    t_next = tn;
-                    if (k_next >= T) active = false;
-                    else request_record(k_next);
+            if constexpr (INLINE_LL) {
+                if (__ballot(reached) != 0ull) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record requested a step ago
+                    const double2 ra = *reinterpret_cast<const double2*>(lds_rec + 2 * lane);
+                    const double2 rb = *reinterpret_cast<const double2*>(lds_rec + 2 * WAVE + 2 * lane);
+                    observe_inline(reached, k_next, ra.x, ra.y, rb.x);
+                    if (reached) {
+                        t = t_next;  // integrate_times re-reads the exact grid time
+                        ++k_next;
+                        t_next = rb.y;
+                        if (k_next >= T) active = false;
+                        else request_record(k_next);
+                    }
                 }
+            } else if (reached) {
+                observe_store(chain_valid, k_next);
+                t = t_next;  // integrate_times re-reads the exact grid time
+                ++k_next;
+                if (k_next >= T) active = false;
+                else t_next = lds_times[k_next];
             }
             if (active && attempts >= pb.max_attempts) { status = 3; active = false; }
         }
@@ -742,47 +767,137 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 #endif
     }
 
-    // ---- 5. total (SEPAIHRDObjectiveFunction.cpp:222-227)
+    // ---- 5. integrator status and step counters; the likelihood pass finishes the evaluation
     if (chain_valid && age == 0) {
-        double total = llH + llICU + llD;
-        if (status == 0 && (isnan(total) || isinf(total))) status = 1;
-        if (status != 0) total = -DBL_MAX;
-        out.loglik[chain] = total;
-        if (out.status) out.status[chain] = status;
-        if (out.n_accept) out.n_accept[chain] = n_acc;
-        if (out.n_reject) out.n_reject[chain] = n_rej;
-        if (out.ll_parts) {
-            out.ll_parts[3 * chain + 0] = llH;
-            out.ll_parts[3 * chain + 1] = llICU;
-            out.ll_parts[3 * chain + 2] = llD;
-#ifdef SEPAIHRD_STAMPS
-            if (grp == 0) {  // cycles: head / RK body / error+controller ; tail goes to chain0+1
-                out.ll_parts[3 * chain + 0] = (double)acc_head;
-                out.ll_parts[3 * chain + 1] = (double)acc_body;
-                out.ll_parts[3 * chain + 2] = (double)acc_err;
+        if constexpr (INLINE_LL) {  // total (SEPAIHRDObjectiveFunction.cpp:222-227)
+            double total = (llH + llICU) + llD;
+            if (status == 0 && (isnan(total) || isinf(total))) status = 1;
+            if (status != 0) total = -DBL_MAX;
+            out.loglik[chain] = total;
+            if (out.status) out.status[chain] = status;
+#ifndef SEPAIHRD_STAMPS
+            if (out.ll_parts) {
+                out.ll_parts[3 * chain + 0] = llH;
+                out.ll_parts[3 * chain + 1] = llICU;
+                out.ll_parts[3 * chain + 2] = llD;
             }
 #endif
+        } else {
+            out.wstatus[chain] = status;  // the likelihood pass finishes the evaluation
         }
+        if (out.n_accept) out.n_accept[chain] = n_acc;
+        if (out.n_reject) out.n_reject[chain] = n_rej;
 #ifdef SEPAIHRD_STAMPS
-        if (out.ll_parts && grp == 1) {
-            out.ll_parts[3 * chain + 0] = (double)acc_tail;
-            out.ll_parts[3 * chain + 1] = (double)attempts;
-            out.ll_parts[3 * chain + 2] = (double)acc_errA;
+        if (out.ll_parts) {
+            double* dbg = out.ll_parts + 3 * chain;
+            if (grp == 0) { dbg[0] = (double)acc_head; dbg[1] = (double)acc_body; dbg[2] = (double)acc_err; }
+            if (grp == 1) { dbg[0] = (double)acc_tail; dbg[1] = (double)attempts; dbg[2] = (double)acc_errA; }
+            if (grp == 2) dbg[0] = (double)acc_tailA;
         }
-        if (out.ll_parts && grp == 2) out.ll_parts[3 * chain + 0] = (double)acc_tailA;
-
 #endif
     }
 }
 
 // ----------------------------------------------------------------------------------
+// Likelihood pass 1: one lane per (chain, age) and one block row per output day.
+// incidence = max(increment, 0), Poisson term
+// obs log(sim + 1e-10) - (sim + 1e-10) for valid observations, summed over the ages of the chain in
+// ascending order (the reference's inner loop, SEPAIHRDObjectiveFunction.cpp:264-276).
+// ----------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(WAVE) void sepaihrd_ll_terms_kernel(const DevProblem pb, const int B,
+                                                                  const EvalOutputs out, const int cum_chains) {
+    const int lane = threadIdx.x;
+    const size_t col = (size_t)blockIdx.x * WAVE + lane;  // chain * LPC + age
+    const int k = blockIdx.y;
+    const size_t stride = (size_t)cum_chains * LPC;
+    const size_t chain = col / LPC;
+    const int age = (int)(col % LPC);
+    const bool valid = chain < (size_t)B;
+    const size_t c = valid ? col : 0;
+    const double* cur = out.cum + (size_t)k * 3 * stride + c;
+    const double* rec = pb.grid + ((size_t)k * LPC + age) * 4;  // {obs_H, obs_ICU, obs_D, t_{k+1}}
+    double rs[3];
+    SEP_UNROLL
+    for (int s = 0; s < 3; ++s) {
+        const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU; streams are H, ICU, D
+        double inc = cur[(size_t)comp * stride];  // X(k) - X(k-1), written by the integrator
+        inc = (inc < 0.0) ? 0.0 : inc;            // cwiseMax(0.0)
+        const double obs = rec[s];
+        const double sim = inc + 1e-10;
+        const double v = obs * log_pos(sim) - sim;
+        const double tv = (valid && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
+        double r = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            ((r += group_bcast<LPC, J + 1>(tv)), ...);
+        }(std::make_integer_sequence<int, LPC - 1>{});
+        rs[s] = r;
+    }
+    if (valid && age == 0) {
+        double* dst = out.rows + (size_t)k * 3 * cum_chains + chain;
+        dst[0] = rs[0];
+        dst[cum_chains] = rs[1];
+        dst[2 * (size_t)cum_chains] = rs[2];
+    }
+}
+
+// Likelihood pass 2: one lane per (chain, stream) adds the daily row sums in day order (the serial
+// "log_likelihood += row_sum" of the reference) and lane 0 of each triple forms
+// total = (hosp + icu) + deaths; NaN / Inf -> lowest() (SEPAIHRDObjectiveFunction.cpp:222-227).
+// The additions are a dependent chain, the loads are not: 16 days are requested at a time.
+__global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProblem pb, const int B,
+                                                                   const EvalOutputs out, const int cum_chains) {
+    // lane = 4 * chain_in_block + stream (stream 3 idles): 16 chains per wave, quad = one chain
+    const int lane = threadIdx.x;
+    const int stream = lane & 3;
+    const int chain = blockIdx.x * 16 + (lane >> 2);
+    const bool valid = chain < B && stream < 3;
+    const int ch = chain < B ? chain : 0;
+    const double* src = out.rows + (size_t)(stream < 3 ? stream : 0) * cum_chains + ch;
+    const size_t step = (size_t)3 * cum_chains;
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 16 <= pb.T; k += 16) {
+        double v[16];
+        SEP_UNROLL
+        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(k + j) * step];
+        SEP_UNROLL
+        for (int j = 0; j < 16; ++j) acc += v[j];
+    }
+    for (; k < pb.T; ++k) acc += src[(size_t)k * step];
+    const double h = group_bcast<4, 0>(acc), i = group_bcast<4, 1>(acc), d = group_bcast<4, 2>(acc);
+    if (!(chain < B) || stream != 0) return;
+    int status = out.wstatus[chain];
+    double total = (h + i) + d;
+    if (status == 0 && (isnan(total) || isinf(total))) status = 1;
+    if (status != 0) total = -DBL_MAX;
+    out.loglik[chain] = total;
+    if (out.status) out.status[chain] = status;
+#ifndef SEPAIHRD_STAMPS
+    if (out.ll_parts) {
+        const bool ok = out.wstatus[chain] == 0;
+        out.ll_parts[3 * chain + 0] = ok ? h : 0.0;
+        out.ll_parts[3 * chain + 1] = ok ? i : 0.0;
+        out.ll_parts[3 * chain + 2] = ok ? d : 0.0;
+    }
+#endif
+    (void)valid;
+}
+
+// ----------------------------------------------------------------------------------
 // launch plumbing
 // ----------------------------------------------------------------------------------
-template <int LPC, int SOLVER, int WPS>
+template <int LPC, int SOLVER, int WPS, bool INLINE_LL>
 int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, const EvalOutputs& out, void* stream) {
     const size_t lds = eval_lds_bytes(pb);
-    hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>), dim3(blocks), dim3(WAVE), lds,
-                       static_cast<hipStream_t>(stream), pb, d_theta, B, out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cum_chains = blocks * (WAVE / LPC);  // columns incl. the shadow groups of the last wave
+    hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>), dim3(blocks), dim3(WAVE), lds,
+                       st, pb, d_theta, B, out, cum_chains);
+    if constexpr (!INLINE_LL) {
+        hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, pb.T), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+        hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -791,18 +906,21 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
+    // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
+    if (blocks <= SPLIT_LL_MAX_BLOCKS) return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1) {
-        // two waves per SIMD only pay when there are two waves for every SIMD (256 CUs x 4 SIMDs)
-        if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2>(pb, d_theta, blocks, B, out, stream);
+        // two waves per SIMD only pay when there are two waves for every SIMD
+        if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
     }
-    return launch_wps<LPC, SOLVER, 1>(pb, d_theta, blocks, B, out, stream);
+    return launch_wps<LPC, SOLVER, 1, true>(pb, d_theta, blocks, B, out, stream);
 }
 
 template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, LaunchInfo* info, const char* name) {
     constexpr int WPS = 1;
+    constexpr bool INLINE_LL = false;
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>)) !=
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>)) !=
         hipSuccess)
         return -3;
     info->vgprs = attr.numRegs;
@@ -810,7 +928,7 @@ int info_one(const DevProblem& pb, LaunchInfo* info, const char* name) {
     info->lds_static = (int)attr.sharedSizeBytes;
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS>, WAVE,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>, WAVE,
                                                      eval_lds_bytes(pb)) != hipSuccess)
         nb = -1;
     info->max_blocks_per_cu = nb;

@@ -57,7 +57,7 @@ class sepaihrd_kernel_info(C.Structure):
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
-    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info",
+    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_reserve",
 )
 
 _lib = None
@@ -98,6 +98,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_eval_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     lib.sepaihrd_get_kernel_info.argtypes = [vp, C.POINTER(sepaihrd_kernel_info)]
+    lib.sepaihrd_reserve.argtypes = [vp, C.c_int]
     if path is None:
         _lib = lib
     return lib
@@ -218,6 +219,9 @@ class HipObjective:
                                                  addr(d_n_accept), addr(d_n_reject), addr(d_ll_parts),
                                                  addr(d_traj), stream if stream else None)
         self._check(rc, "sepaihrd_eval_batch_device")
+
+    def reserve(self, max_B: int):
+        self._check(self.lib.sepaihrd_reserve(self.ctx, int(max_B)), "sepaihrd_reserve")
 
     def apply_constraints(self, theta, mode: int) -> np.ndarray:
         th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)

@@ -187,3 +187,94 @@ def test_host_objective_fails_loudly_without_gpu(mm, shipped, have_gpu):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no HIP device"):
         mm.HostObjective(shipped)
+
+
+# ---- sepaihrd_create argument validation happens before any device call: testable without a GPU
+def _create_error(mm, pb, patch=None):
+    import ctypes as C
+    lib = mm.load_library()
+    keep = []
+    st = mm.hipabi.build_problem_struct(pb, keep)
+    if patch:
+        patch(st, keep)
+    err = C.create_string_buffer(512)
+    ctx = lib.sepaihrd_create(C.byref(st), -1, err, len(err))
+    if ctx:
+        lib.sepaihrd_destroy(ctx)
+        return None
+    return err.value.decode()
+
+
+def test_create_validates_like_the_reference_constructors(mm, shipped, have_gpu):
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+
+    def times_not_increasing(st, keep):   # Simulator::run: "Output time points must be strictly increasing"
+        t = np.array(shipped.times)
+        t[5] = t[4]
+        keep.append(t)
+        st.times = t.ctypes.data_as(dp)
+    assert "strictly increasing" in _create_error(mm, shipped, times_not_increasing)
+
+    def bad_abi(st, keep):
+        st.abi_version = 99
+    assert "ABI version" in _create_error(mm, shipped, bad_abi)
+
+    def no_kappa(st, keep):               # the model always owns an NPI strategy with a baseline period
+        st.n_kappa = 0
+    assert "schedule" in _create_error(mm, shipped, no_kappa)
+
+    def negative_baseline_end(st, keep):  # PiecewiseConstantNpiStrategy ctor
+        k = np.array(shipped.kappa_end_times)
+        k[0] = -1.0
+        keep.append(k)
+        st.kappa_end_times = k.ctypes.data_as(dp)
+    assert "non-negative" in _create_error(mm, shipped, negative_baseline_end)
+
+    def unsorted_beta(st, keep):          # PiecewiseConstantParameterStrategy ctor
+        b = np.array(shipped.beta_end_times)
+        b[2] = b[1]
+        keep.append(b)
+        st.beta_end_times = b.ctypes.data_as(dp)
+    assert "beta end times" in _create_error(mm, shipped, unsorted_beta)
+
+    def negative_tolerance(st, keep):     # Simulator::setErrorTolerance
+        st.abs_err = -1e-6
+    assert "tolerance" in _create_error(mm, shipped, negative_tolerance)
+
+    def zero_dt(st, keep):                # Simulator ctor: "Time step hint must be positive"
+        st.dt_hint = 0.0
+    assert "dt_hint" in _create_error(mm, shipped, zero_dt)
+
+    def bad_solver(st, keep):
+        st.solver = 7
+    assert "solver" in _create_error(mm, shipped, bad_solver)
+
+    def too_many_ages(st, keep):
+        st.n_age = 65
+    assert "n_age" in _create_error(mm, shipped, too_many_ages)
+
+    def null_pointer(st, keep):
+        st.obs_H = None
+    assert "NULL" in _create_error(mm, shipped, null_pointer)
+
+    def beta_index_out_of_range(st, keep):   # "Beta index out of range for name"
+        idx = np.array(mm.hipabi.np.ctypeslib.as_array(st.param_index, (shipped.n_params,)))
+        idx[0] = 99
+        keep.append(idx)
+        st.param_index = idx.ctypes.data_as(C.POINTER(C.c_int32))
+    if have_gpu:   # field-map checks run after the device check
+        assert "beta index" in _create_error(mm, shipped, beta_index_out_of_range)
+    # a valid problem fails only for lack of a device on the CPU box
+    msg = _create_error(mm, shipped)
+    assert (msg is None) if have_gpu else ("no HIP device" in msg)
+
+
+def test_null_ctx_and_bad_arguments_return_error_codes(mm):
+    lib = mm.load_library()
+    assert lib.sepaihrd_eval_batch(None, None, 1, None, None, None, None, None, None) == -1
+    assert lib.sepaihrd_eval_batch_device(None, None, 1, None, None, None, None, None, None, None) == -1
+    assert lib.sepaihrd_set_constraint_mode(None, 0) == -1
+    assert lib.sepaihrd_apply_constraints(None, 0, None, 1, None) == -1
+    assert lib.sepaihrd_last_error(None) == b"ctx is NULL"
+    lib.sepaihrd_destroy(None)   # no-op
