@@ -151,9 +151,11 @@ def main():
         hip.eval_batch_device(pools[i % n_pool], d_ll, d_status=d_status, d_n_accept=d_acc, d_n_reject=d_rej,
                               stream=stream.cuda_stream, B=B)
 
+    hip.reserve(B)
     for i in range(W):
         step(i)
     torch.cuda.synchronize(dev)
+    hip.set_timing(True)  # HIP events around the integrator kernel and the likelihood pass, on the launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -168,7 +170,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(K, 1)
+    step_ms = ev0.elapsed_time(ev1) / max(K, 1)
+    tm = hip.get_timing()
+    hip.set_timing(False)
+    kernel_ms = tm["integrator_ms"] / max(tm["launches"], 1)      # dominant kernel: sepaihrd_eval_kernel
+    ll_pass_ms = tm["likelihood_ms"] / max(tm["launches"], 1)     # ll_terms + ll_reduce (0 when inline)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -214,7 +220,9 @@ def main():
         evals_total = world * B * K
         value = evals_total / elapsed_max
         info = hip.kernel_info()
-        bytes_eval = 8 * P + 16 + problem_bytes(pb) / B
+        bytes_eval = 8 * P + 16 + problem_bytes(pb) / B        # theta in, loglik + counters out
+        split_ll = -(-B // info["chains_per_wave"]) <= 1024   # batches that do not fill the chip park increments
+        ws_bytes_eval = pb.n_times * 3 * pb.n * 8 if split_ll else 0
         bytes_launch = bytes_eval * B
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
         flops_eval = algorithmic_flops_per_eval(pb.n, float(acc.mean()), pb.n_obs)
@@ -246,8 +254,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": info["kernel_name"], "kernel_ms": kernel_ms,
+                "kernel": info["kernel_name"], "kernel_ms": kernel_ms, "likelihood_pass_ms": ll_pass_ms,
+                "step_ms_on_stream": step_ms,
                 "algorithmic_bytes_per_eval": bytes_eval,
+                "likelihood_workspace_bytes_per_eval": ws_bytes_eval,
+                "achieved_incl_workspace": (bytes_eval + ws_bytes_eval) * B / (kernel_ms * 1e-3) / 1e9,
                 "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d): see fp64_valu",
                 "fp64_valu": {"achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,

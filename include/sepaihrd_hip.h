@@ -186,6 +186,13 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx *ctx, const double *d_theta, int B, 
                                int32_t *d_status, int32_t *d_n_accept, int32_t *d_n_reject,
                                double *d_ll_parts, double *d_traj, void *stream);
 
+/* Per-kernel timing for benchmarks: while enabled every eval_batch_device launch is bracketed by HIP
+ * events on its stream (before the integrator kernel, after it, after the likelihood pass).
+ * sepaihrd_get_timing synchronises on them, returns the summed milliseconds of the integrator kernel
+ * and of the likelihood pass over the launches since the last call, and resets the counters. */
+int sepaihrd_set_timing(sepaihrd_ctx *ctx, int enable);
+int sepaihrd_get_timing(sepaihrd_ctx *ctx, double *integrator_ms, double *likelihood_ms, int *launches);
+
 /* Pre-allocate the workspace for batches of up to max_B chains. */
 int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
 

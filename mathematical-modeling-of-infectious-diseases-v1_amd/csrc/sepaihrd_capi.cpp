@@ -46,6 +46,10 @@ struct sepaihrd_ctx {
     double* ws_rows = nullptr;
     int32_t* ws_status = nullptr;
     size_t ws_budget_bytes = (size_t)24 << 30;  // larger batches are evaluated in chunks of chains
+    // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // triples: before integrator, after integrator, after likelihood pass
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -357,6 +361,7 @@ void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_staging(ctx);
     free_workspace(ctx);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
 }
@@ -405,13 +410,24 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
     const size_t traj_per_chain = (size_t)ctx->T * NUM_COMP * ctx->n;
     for (size_t off = 0; off < (size_t)B; off += chunk) {
         const int nb = (int)std::min(chunk, (size_t)B - off);
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (ctx->timing) {
+            while (ctx->ev.size() < ctx->ev_used + 3) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e), ctx, return SEPAIHRD_E_HIP);
+                ctx->ev.push_back(e);
+            }
+            e0 = ctx->ev[ctx->ev_used]; e1 = ctx->ev[ctx->ev_used + 1]; e2 = ctx->ev[ctx->ev_used + 2];
+            ctx->ev_used += 3;
+            (void)hipEventRecord(e0, static_cast<hipStream_t>(stream));
+        }
         EvalOutputs out{d_loglik + off,
                         d_status ? d_status + off : nullptr,
                         d_n_accept ? d_n_accept + off : nullptr,
                         d_n_reject ? d_n_reject + off : nullptr,
                         d_ll_parts ? d_ll_parts + 3 * off : nullptr,
                         d_traj ? d_traj + off * traj_per_chain : nullptr,
-                        ctx->ws_cum, ctx->ws_rows, ctx->ws_status};
+                        ctx->ws_cum, ctx->ws_rows, ctx->ws_status, e1};
         const double* th = d_theta + off * (size_t)ctx->P;
         const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
                                                          : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
@@ -419,7 +435,31 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
             ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
             return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
         }
+        if (e2) (void)hipEventRecord(e2, static_cast<hipStream_t>(stream));
     }
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_set_timing(sepaihrd_ctx* ctx, int enable) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    ctx->timing = enable != 0;
+    ctx->ev_used = 0;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_get_timing(sepaihrd_ctx* ctx, double* integrator_ms, double* likelihood_ms, int* launches) {
+    if (!ctx || !integrator_ms || !likelihood_ms || !launches) return SEPAIHRD_E_INVALID_ARG;
+    double a = 0.0, b = 0.0;
+    const size_t n = ctx->ev_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float m0 = 0.f, m1 = 0.f;
+        HIP_TRY(hipEventSynchronize(ctx->ev[3 * i + 2]), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventElapsedTime(&m0, ctx->ev[3 * i], ctx->ev[3 * i + 1]), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventElapsedTime(&m1, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]), ctx, return SEPAIHRD_E_HIP);
+        a += m0; b += m1;
+    }
+    *integrator_ms = a; *likelihood_ms = b; *launches = (int)n;
+    ctx->ev_used = 0;
     return SEPAIHRD_OK;
 }
 

@@ -66,6 +66,7 @@ struct EvalOutputs {
     double* cum;
     double* rows;
     int32_t* wstatus;
+    void* ev_after_integrator;  // optional hipEvent_t recorded between the integrator kernel and the likelihood pass
 };
 inline size_t workspace_cum_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains * pb.lpc; }
 inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains; }

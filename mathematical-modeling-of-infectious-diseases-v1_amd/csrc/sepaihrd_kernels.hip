@@ -894,6 +894,7 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
     const int cum_chains = blocks * (WAVE / LPC);  // columns incl. the shadow groups of the last wave
     hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>), dim3(blocks), dim3(WAVE), lds,
                        st, pb, d_theta, B, out, cum_chains);
+    if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
         hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, pb.T), dim3(WAVE), 0, st, pb, B, out, cum_chains);
         hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains);

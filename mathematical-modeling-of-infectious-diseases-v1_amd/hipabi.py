@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
     "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_reserve",
+    "sepaihrd_set_timing", "sepaihrd_get_timing",
 )
 
 _lib = None
@@ -99,6 +100,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     lib.sepaihrd_get_kernel_info.argtypes = [vp, C.POINTER(sepaihrd_kernel_info)]
     lib.sepaihrd_reserve.argtypes = [vp, C.c_int]
+    lib.sepaihrd_set_timing.argtypes = [vp, C.c_int]
+    lib.sepaihrd_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     if path is None:
         _lib = lib
     return lib
@@ -219,6 +222,14 @@ class HipObjective:
                                                  addr(d_n_accept), addr(d_n_reject), addr(d_ll_parts),
                                                  addr(d_traj), stream if stream else None)
         self._check(rc, "sepaihrd_eval_batch_device")
+
+    def set_timing(self, enable: bool):
+        self._check(self.lib.sepaihrd_set_timing(self.ctx, int(enable)), "sepaihrd_set_timing")
+
+    def get_timing(self) -> dict:
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        self._check(self.lib.sepaihrd_get_timing(self.ctx, C.byref(a), C.byref(b), C.byref(n)), "sepaihrd_get_timing")
+        return {"integrator_ms": a.value, "likelihood_ms": b.value, "launches": n.value}
 
     def reserve(self, max_B: int):
         self._check(self.lib.sepaihrd_reserve(self.ctx, int(max_B)), "sepaihrd_reserve")
