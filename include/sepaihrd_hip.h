@@ -33,9 +33,9 @@
  *                              Poisson log-likelihood (:241-279, serial row order).
  *   sepaihrd_apply_constraints IParameterManager::applyConstraints
  *                              (SEPAIHRDParameterManager.cpp:315-347)
- *   sepaihrd_mh_*              MetropolisHastingsSampler::optimize run for many
- *                              independent chains in lock-step
- *                              (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:201-412)
+ * The lock-step multi-chain MetropolisHastingsSampler::optimize
+ * (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:201-412) is a
+ * CALLER of this boundary and lives in the C++ host library (host/), not here.
  *
  * Error convention: functions return 0 on success or a negative SEPAIHRD_E_* code;
  * nothing throws across this boundary.  Per-chain model failures never fail the
