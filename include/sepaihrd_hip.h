@@ -196,6 +196,36 @@ int sepaihrd_get_timing(sepaihrd_ctx *ctx, double *integrator_ms, double *likeli
 /* Pre-allocate the workspace for batches of up to max_B chains. */
 int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
 
+/* ---- posterior ensemble (second consumer of the integrator) ----
+ *
+ * sepaihrd_set_initial_state_mode: SEPAIHRD_INIT_FROM_THETA (default) derives x(t0) from theta as
+ * SEPAIHRDObjectiveFunction::calculate does (run-up / multiplier branch, S by subtraction,
+ * src/model/objectives/SEPAIHRDObjectiveFunction.cpp:124-163); SEPAIHRD_INIT_FIXED integrates every
+ * theta from problem.initial_state exactly as given, which is what
+ * SimulationRunner::runSimulation(params, initial_state, time_points) does for the post-calibration
+ * ensemble (src/model/SimulationRunner.cpp:24-104).
+ *
+ * sepaihrd_ensemble_quantiles: one simulation per posterior sample theta[s] (S x n_params, host),
+ * then, for every output time t >= 0 and age class, the quantiles across samples of
+ *   series 0..2  daily hospitalisations / ICU admissions / deaths  max(0, X(t) - X(t_prev))
+ *   series 3..5  their running sums in time order
+ * (ResultAggregator::aggregatePosteriorPredictives, src/model/ResultAggregator.cpp:297-345) and, if
+ * sero_quantiles != NULL, of the seroprevalence (sum N - sum_a S_a(t)) / sum N at EVERY output time
+ * (MetricsCalculator::calculateSeroprevalenceTrajectory, src/model/MetricsCalculator.cpp:199-226).
+ * Quantile rule = exact sort + linear interpolation at q (n_valid - 1)
+ * (PostCalibrationAnalyser.cpp:303-340); samples whose integration failed are skipped like the
+ * reference's `if (!sim_result.isValid()) continue`.
+ *   ppc_quantiles   [6][n_probs][T_pos][n_age]   T_pos = number of output times >= 0
+ *   sero_quantiles  [n_probs][n_times] or NULL
+ *   status          [S] integrator status per sample, or NULL;  n_valid: count of status 0, or NULL
+ * S <= 16384 (one sorted segment lives in LDS); larger ensembles: SEPAIHRD_E_UNSUPPORTED. */
+#define SEPAIHRD_INIT_FROM_THETA 0
+#define SEPAIHRD_INIT_FIXED 1
+int sepaihrd_set_initial_state_mode(sepaihrd_ctx *ctx, int mode);
+int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, const double *probs,
+                                int n_probs, double *ppc_quantiles, double *sero_quantiles,
+                                int32_t *status, int32_t *n_valid);
+
 /* applyConstraints for B vectors on the host (exactly the device's arithmetic). */
 int sepaihrd_apply_constraints(const sepaihrd_ctx *ctx, int mode, const double *in, int B, double *out);
 

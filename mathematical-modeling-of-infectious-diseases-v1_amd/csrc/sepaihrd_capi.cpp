@@ -28,6 +28,7 @@ struct sepaihrd_ctx {
     std::vector<double> lower, upper;
     std::vector<uint8_t> has_bounds;
     int n = 0, T = 0, P = 0;
+    std::vector<double> host_N;  // population sizes (ensemble seroprevalence)
     std::string last_error;
     // staging buffers for the host-pointer entry point (grown on demand)
     size_t cap_B = 0;
@@ -204,6 +205,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
     ctx->solver = pb->solver;
     ctx->arith = pb->arith == SEPAIHRD_ARITH_FMA ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT;
     ctx->n = n; ctx->T = T; ctx->P = P;
+    ctx->host_N.assign(pb->N, pb->N + n);
 
     const int lpc = lanes_per_chain(n);
     const int ns = SS_SCHEDULE0 + nb + nk;
@@ -427,7 +429,7 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
                         d_n_reject ? d_n_reject + off : nullptr,
                         d_ll_parts ? d_ll_parts + 3 * off : nullptr,
                         d_traj ? d_traj + off * traj_per_chain : nullptr,
-                        ctx->ws_cum, ctx->ws_rows, ctx->ws_status, e1};
+                        ctx->ws_cum, ctx->ws_rows, ctx->ws_status, e1, 0};
         const double* th = d_theta + off * (size_t)ctx->P;
         const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
                                                          : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
@@ -518,6 +520,106 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
     if (traj)
         HIP_TRY(hipMemcpy(traj, ctx->d_traj, traj_elems * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
+    if (!ctx || (mode != SEPAIHRD_INIT_FROM_THETA && mode != SEPAIHRD_INIT_FIXED)) return SEPAIHRD_E_INVALID_ARG;
+    ctx->dp.init_mode = mode;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, const double* probs, int n_probs,
+                                double* ppc_quantiles, double* sero_quantiles, int32_t* status, int32_t* n_valid) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    if (S <= 0 || !theta || !probs || n_probs <= 0 || n_probs > 1024 || !ppc_quantiles) {
+        ctx->last_error = "ensemble_quantiles: need S > 0, theta, probs (1..1024) and ppc_quantiles";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    if (S > ENSEMBLE_MAX_SAMPLES) {
+        ctx->last_error = "ensemble_quantiles: at most 16384 samples per call (sorted segment lives in LDS)";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
+    for (int p = 0; p < n_probs; ++p)
+        if (!(probs[p] >= 0.0 && probs[p] <= 1.0)) {
+            ctx->last_error = "ensemble_quantiles: probabilities must lie in [0, 1]";
+            return SEPAIHRD_E_INVALID_ARG;
+        }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const DevProblem& dp = ctx->dp;
+    const int Tp = dp.T - dp.runup_offset;
+    if (Tp <= 0) {
+        ctx->last_error = "ensemble_quantiles: no output time >= 0";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    int S_pad = WAVE;
+    while (S_pad < S) S_pad <<= 1;
+    const size_t cpw = (size_t)(WAVE / dp.lpc);
+    const size_t chains = ((size_t)S + cpw - 1) / cpw * cpw;
+    int rc = ensure_workspace(ctx, chains);
+    if (rc != SEPAIHRD_OK) return rc;
+
+    const bool want_sero = sero_quantiles != nullptr;
+    const size_t n_ppc = (size_t)6 * n_probs * Tp * dp.n;
+    const size_t n_sero = want_sero ? (size_t)n_probs * dp.T : 0;
+    const size_t n_vals = ((size_t)6 * Tp * dp.n + (want_sero ? dp.T : 0)) * S_pad;
+    const size_t n_traj = want_sero ? (size_t)S * dp.T * NUM_COMP * dp.n : 0;
+    double *d_theta = nullptr, *d_ll = nullptr, *d_vals = nullptr, *d_traj = nullptr, *d_probs = nullptr, *d_q = nullptr;
+    int32_t* d_nv = nullptr;
+    std::vector<void*> tmp;
+    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+    auto dalloc = [&](void** p, size_t bytes) {
+        if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) return false;
+        tmp.push_back(*p);
+        return true;
+    };
+    if (!dalloc((void**)&d_theta, (size_t)S * ctx->P * sizeof(double)) || !dalloc((void**)&d_ll, (size_t)S * sizeof(double)) ||
+        !dalloc((void**)&d_vals, n_vals * sizeof(double)) || !dalloc((void**)&d_traj, n_traj * sizeof(double)) ||
+        !dalloc((void**)&d_probs, (size_t)n_probs * sizeof(double)) || !dalloc((void**)&d_q, (n_ppc + n_sero) * sizeof(double)) ||
+        !dalloc((void**)&d_nv, sizeof(int32_t))) {
+        cleanup();
+        ctx->last_error = "ensemble_quantiles: device allocation failed";
+        return SEPAIHRD_E_HIP;
+    }
+    HIP_TRY(hipMemcpy(d_theta, theta, (size_t)S * ctx->P * sizeof(double), hipMemcpyHostToDevice), ctx,
+            { cleanup(); return SEPAIHRD_E_HIP; });
+    HIP_TRY(hipMemcpy(d_probs, probs, (size_t)n_probs * sizeof(double), hipMemcpyHostToDevice), ctx,
+            { cleanup(); return SEPAIHRD_E_HIP; });
+    EvalOutputs out{d_ll, nullptr, nullptr, nullptr, nullptr, want_sero ? d_traj : nullptr,
+                    ctx->ws_cum, ctx->ws_rows, ctx->ws_status, nullptr, 1};
+    rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(dp, ctx->solver, d_theta, S, out, nullptr)
+                                          : launch_eval_strict(dp, ctx->solver, d_theta, S, out, nullptr);
+    if (rc != 0) {
+        cleanup();
+        ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
+        return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
+    }
+    double total_pop = 0.0;
+    for (int i = 0; i < dp.n; ++i) total_pop += ctx->host_N[(size_t)i];
+    EnsembleArgs a{};
+    a.S = S; a.S_pad = S_pad; a.lpc = dp.lpc; a.n = dp.n; a.T = dp.T; a.Tp = Tp; a.runup_offset = dp.runup_offset;
+    a.n_probs = n_probs;
+    a.cum_stride = chains * dp.lpc;
+    a.cum = ctx->ws_cum; a.wstatus = ctx->ws_status; a.traj = want_sero ? d_traj : nullptr;
+    a.total_pop = total_pop;
+    a.vals = d_vals; a.probs = d_probs; a.q_out = d_q; a.sero_out = want_sero ? d_q + n_ppc : nullptr; a.n_valid = d_nv;
+    rc = launch_ensemble_summaries(a, nullptr);
+    if (rc != 0) {
+        cleanup();
+        ctx->last_error = "ensemble summary launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    HIP_TRY(hipDeviceSynchronize(), ctx, { cleanup(); return SEPAIHRD_E_HIP; });
+    HIP_TRY(hipMemcpy(ppc_quantiles, d_q, n_ppc * sizeof(double), hipMemcpyDeviceToHost), ctx, { cleanup(); return SEPAIHRD_E_HIP; });
+    if (want_sero)
+        HIP_TRY(hipMemcpy(sero_quantiles, d_q + n_ppc, n_sero * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                { cleanup(); return SEPAIHRD_E_HIP; });
+    if (status)
+        HIP_TRY(hipMemcpy(status, ctx->ws_status, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
+                { cleanup(); return SEPAIHRD_E_HIP; });
+    if (n_valid)
+        HIP_TRY(hipMemcpy(n_valid, d_nv, sizeof(int32_t), hipMemcpyDeviceToHost), ctx, { cleanup(); return SEPAIHRD_E_HIP; });
+    cleanup();
     return SEPAIHRD_OK;
 }
 

@@ -25,6 +25,7 @@ enum VecField { VF_A = 0, VF_H_INFEC, VF_P, VF_H, VF_ICU, VF_D_H, VF_D_ICU, VF_D
 struct DevProblem {
     int32_t n, lpc, T, n_obs, runup_offset, nb, nk, P, ns;
     int32_t constraint_mode, kappa_calibrated, max_attempts, obs_rows_match;
+    int32_t init_mode;  // 0: initial state derived from theta (objective), 1: problem.initial_state as given (ensemble runs)
     double abs_tol, rel_tol, dt_hint, max_gap;
     const double* times;         // [T]
     // per output point k and lane (age): {obs_H, obs_ICU, obs_D, times[k+1]} -- 32 bytes, fetched by
@@ -67,6 +68,7 @@ struct EvalOutputs {
     double* rows;
     int32_t* wstatus;
     void* ev_after_integrator;  // optional hipEvent_t recorded between the integrator kernel and the likelihood pass
+    int32_t force_split;        // always park the increments in `cum` (ensemble summaries read them)
 };
 inline size_t workspace_cum_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains * pb.lpc; }
 inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains; }
@@ -83,6 +85,26 @@ int launch_eval_fma(const DevProblem& pb, int solver, const double* d_theta, int
                     const EvalOutputs& out, void* stream);
 int kernel_info_strict(const DevProblem& pb, int solver, LaunchInfo* info);
 int kernel_info_fma(const DevProblem& pb, int solver, LaunchInfo* info);
+
+// ---- posterior ensemble summaries (csrc/sepaihrd_ensemble.hip) ----
+constexpr int ENSEMBLE_MAX_SAMPLES = 16384;  // one sorted segment lives in LDS (128 KiB of 160 KiB)
+struct EnsembleArgs {
+    int S, S_pad;             // samples, padded to a power of two >= 64
+    int lpc, n, T, Tp;        // lanes per chain, ages, output times, output times with t >= 0
+    int runup_offset;         // index of the first output time >= 0
+    int n_probs;
+    size_t cum_stride;        // columns of the integrator workspace (launch chains * lpc)
+    const double* cum;        // [T][3][cum_stride] daily increments of D, CumH, CumICU
+    const int32_t* wstatus;   // [S] integrator status
+    const double* traj;       // [S][T][11][n] or null (seroprevalence needs S(t))
+    double total_pop;
+    double* vals;             // [(6 Tp n) + T][S_pad] series values, one sortable segment per row
+    const double* probs;      // [n_probs] device
+    double* q_out;            // [6][n_probs][Tp][n] device
+    double* sero_out;         // [n_probs][T] device or null
+    int32_t* n_valid;         // [1] device
+};
+int launch_ensemble_summaries(const EnsembleArgs& a, void* stream);
 
 inline int lanes_per_chain(int n) {
     int l = 1;

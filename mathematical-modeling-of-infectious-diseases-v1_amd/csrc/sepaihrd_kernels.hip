@@ -433,13 +433,13 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         for (int k = 1; k < pb.nk; ++k) neg |= (scalar_slot(SS_SCHEDULE0 + pb.nb + k) < 0.0);
         if (neg) status = 1;
     }
-    if (!pb.obs_rows_match) status = 1;  // SEPAIHRDObjectiveFunction.cpp:176-178
+    if (!pb.obs_rows_match && pb.init_mode == 0) status = 1;  // SEPAIHRDObjectiveFunction.cpp:176-178
 
     // ---- 3. initial state (SEPAIHRDObjectiveFunction.cpp:124-163)
     double x[NUM_COMP];
     SEP_UNROLL
     for (int c = 0; c < NUM_COMP; ++c) x[c] = pb.init_state[c * LPC + age];
-    {
+    if (pb.init_mode == 0) {
         const double runup_days = scalar_slot(SS_RUNUP_DAYS);
         const double seed_exposed = scalar_slot(SS_SEED_EXPOSED);
         if (runup_days > 0 && seed_exposed > 0) {
@@ -908,7 +908,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
-    if (blocks <= SPLIT_LL_MAX_BLOCKS) return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
+    if (blocks <= SPLIT_LL_MAX_BLOCKS || out.force_split) return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1) {
         // two waves per SIMD only pay when there are two waves for every SIMD
         if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);

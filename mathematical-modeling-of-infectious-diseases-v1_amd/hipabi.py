@@ -58,7 +58,8 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
     "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_reserve",
-    "sepaihrd_set_timing", "sepaihrd_get_timing",
+    "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
+    "sepaihrd_ensemble_quantiles",
 )
 
 _lib = None
@@ -102,6 +103,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_reserve.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_timing.argtypes = [vp, C.c_int]
     lib.sepaihrd_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.sepaihrd_set_initial_state_mode.argtypes = [vp, C.c_int]
+    lib.sepaihrd_ensemble_quantiles.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -230,6 +233,29 @@ class HipObjective:
         a, b, n = C.c_double(), C.c_double(), C.c_int()
         self._check(self.lib.sepaihrd_get_timing(self.ctx, C.byref(a), C.byref(b), C.byref(n)), "sepaihrd_get_timing")
         return {"integrator_ms": a.value, "likelihood_ms": b.value, "launches": n.value}
+
+    def set_initial_state_mode(self, mode: int):
+        """0: x(t0) derived from theta (objective); 1: problem.initial_state as given (ensemble runs)."""
+        self._check(self.lib.sepaihrd_set_initial_state_mode(self.ctx, int(mode)), "set_initial_state_mode")
+
+    def ensemble_quantiles(self, theta, probs, want_sero: bool = True) -> dict:
+        """Posterior-ensemble summaries (ResultAggregator.cpp:297-345, MetricsCalculator.cpp:199-226):
+        ppc [6][n_probs][T_pos][n], sero [n_probs][T], status [S], n_valid."""
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        pr = np.ascontiguousarray(probs, dtype=np.float64)
+        S, npb = th.shape[0], pr.size
+        Tp = int(np.sum(np.asarray(self.pb.times) >= 0.0))
+        ppc = np.empty((6, npb, Tp, self.pb.n))
+        sero = np.empty((npb, self.pb.n_times)) if want_sero else None
+        status = np.empty(S, dtype=np.int32)
+        nv = C.c_int32(0)
+        self._check(self.lib.sepaihrd_ensemble_quantiles(
+            self.ctx, th.ctypes.data, S, pr.ctypes.data, npb, ppc.ctypes.data,
+            sero.ctypes.data if want_sero else None, status.ctypes.data, C.byref(nv)), "ensemble_quantiles")
+        out = {"ppc": ppc, "status": status, "n_valid": nv.value}
+        if want_sero:
+            out["sero"] = sero
+        return out
 
     def reserve(self, max_B: int):
         self._check(self.lib.sepaihrd_reserve(self.ctx, int(max_B)), "sepaihrd_reserve")

@@ -212,6 +212,18 @@ int oracle_mh(void* hv, int iterations, int burn_in, int adaptation_period, int 
     return 0;
 }
 
+int oracle_ensemble(void* hv, const double* theta, int S, const double* probs, int n_probs, double* ppc,
+                    double* sero, int32_t* status, int32_t* n_valid, int nthreads) {
+    auto* h = static_cast<Handle*>(hv);
+    const oracle::EnsembleSummary r = oracle::ensemble_summaries(
+        h->pb, theta, S, std::vector<double>(probs, probs + n_probs), nthreads > 0 ? nthreads : 1);
+    std::copy(r.ppc.begin(), r.ppc.end(), ppc);
+    if (sero) std::copy(r.sero.begin(), r.sero.end(), sero);
+    if (status) std::copy(r.status.begin(), r.status.end(), status);
+    if (n_valid) *n_valid = r.n_valid;
+    return r.Tp;
+}
+
 int oracle_num_threads(void) {
 #if defined(_OPENMP)
     return omp_get_max_threads();

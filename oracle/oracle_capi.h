@@ -50,6 +50,10 @@ int oracle_mh(void *h, int iterations, int burn_in, int adaptation_period, int t
               double *best, double *best_value, int32_t *accepted, double *final_scale,
               unsigned char *accept_trace, double *samples, double *sample_values,
               int32_t *n_samples, double *final_cov);
+/* Posterior ensemble summaries from a FIXED initial state (SimulationRunner::runSimulation):
+ * ppc [6][n_probs][Tp][n], sero [n_probs][T], status [S]; returns Tp, n_valid via pointers. */
+int oracle_ensemble(void *h, const double *theta, int S, const double *probs, int n_probs, double *ppc,
+                    double *sero, int32_t *status, int32_t *n_valid, int nthreads);
 int oracle_num_threads(void);
 
 #ifdef __cplusplus

@@ -69,6 +69,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_mh.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
         _lib = lib
     return lib
@@ -115,6 +116,7 @@ class Oracle:
         if not self.h:
             raise RuntimeError("oracle_create failed: " + err.value.decode())
         self.P, self.n, self.T = pb.n_params, pb.n, pb.n_times
+        self.times = np.asarray(pb.times, dtype=np.float64)
 
     def __del__(self):
         try:
@@ -147,6 +149,23 @@ class Oracle:
         if want_traj:
             out["traj"] = traj
         return out
+
+    def ensemble_quantiles(self, theta, probs, nthreads: int = 0) -> dict:
+        """Posterior-ensemble summaries from the problem's initial state as given (fixed-state runs)."""
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        pr = np.ascontiguousarray(probs, dtype=np.float64)
+        S, npb = th.shape[0], pr.size
+        Tp = int(np.sum(np.asarray(self.times) >= 0.0))
+        ppc = np.empty((6, npb, Tp, self.n))
+        sero = np.empty((npb, self.T))
+        status = np.empty(S, dtype=np.int32)
+        nv = C.c_int32(0)
+        if nthreads <= 0:
+            nthreads = self.lib.oracle_num_threads()
+        tp = self.lib.oracle_ensemble(self.h, th.ctypes.data, S, pr.ctypes.data, npb, ppc.ctypes.data,
+                                      sero.ctypes.data, status.ctypes.data, C.byref(nv), nthreads)
+        assert tp == Tp
+        return {"ppc": ppc, "sero": sero, "status": status, "n_valid": nv.value}
 
     def calculate(self, theta) -> float:
         return float(self.eval_batch(theta, nthreads=1)["loglik"][0])

@@ -752,6 +752,119 @@ inline double objective(const Problem& pb, const std::vector<double>& theta, Eva
 }
 
 // -----------------------------------------------------------------------------
+// Posterior ensemble (second consumer of the integrator).
+//   SimulationRunner::runSimulation       src/model/SimulationRunner.cpp:24-104
+//     theta -> model (updateModelParameters, PostCalibrationAnalyser.cpp:212-218), then the
+//     simulation starts from the GIVEN initial state: no run-up / multiplier re-derivation.
+//   ResultAggregator::aggregatePosteriorPredictives  src/model/ResultAggregator.cpp:297-345
+//     daily = max(0, X(t) - X(t_prev)) on the output times >= 0, cumulative = running sums.
+//   MetricsCalculator::calculateSeroprevalenceTrajectory  src/model/MetricsCalculator.cpp:199-226
+//   quantile rule  PostCalibrationAnalyser.cpp:303-340 (exact sort, interpolate at q (n - 1)).
+// The reference estimates the incidence quantiles with Boost.Accumulators' P^2 (third-party,
+// order-dependent); this restatement and the device path use the exact-sort rule throughout.
+// -----------------------------------------------------------------------------
+inline int simulate_sample(const Problem& pb, const std::vector<double>& theta, std::vector<double>& traj) {
+    Model model(pb.base);
+    try {
+        pb.pm.updateModelParameters(theta, model);
+    } catch (...) { return 1; }
+    thread_local SimulationResult res;
+    StepStats st;
+    st.max_attempts = pb.max_attempts;
+    try {
+        simulate(res, model, pb.initial_state, pb.time_points, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &st);
+    } catch (const step_adjustment_error&) { return 2;
+    } catch (const step_budget_error&) { return 3; }
+    traj = res.flat;
+    return 0;
+}
+
+inline double sorted_quantile(const std::vector<double>& v, double q) {
+    const double pos = q * (v.size() - 1);
+    const size_t idx = static_cast<size_t>(pos);
+    const double frac = pos - idx;
+    if (idx + 1 < v.size()) return v[idx] * (1.0 - frac) + v[idx + 1] * frac;
+    return v[idx];
+}
+
+struct EnsembleSummary {
+    int Tp = 0, n_valid = 0;
+    std::vector<double> ppc;     // [6][n_probs][Tp][n]
+    std::vector<double> sero;    // [n_probs][T]
+    std::vector<int> status;     // [S]
+};
+
+inline EnsembleSummary ensemble_summaries(const Problem& pb, const double* thetas, int S,
+                                          const std::vector<double>& probs, int nthreads = 1) {
+    const std::vector<double>& tp = pb.time_points;
+    const int T = static_cast<int>(tp.size()), n = pb.base.n, P = static_cast<int>(pb.pm.names.size());
+    std::vector<int> pos_idx;
+    for (int i = 0; i < T; ++i)
+        if (tp[i] >= 0.0) pos_idx.push_back(i);
+    EnsembleSummary out;
+    const int Tp = out.Tp = static_cast<int>(pos_idx.size());
+    const int np = static_cast<int>(probs.size());
+    out.status.assign(S, 0);
+    double total_pop = 0.0;
+    for (int i = 0; i < n; ++i) total_pop += pb.base.N[i];
+    // per-sample series, sample-major
+    std::vector<double> series(static_cast<size_t>(S) * 6 * Tp * n), sero(static_cast<size_t>(S) * T);
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic)
+    for (int s = 0; s < S; ++s) {
+        std::vector<double> theta(thetas + static_cast<size_t>(s) * P, thetas + static_cast<size_t>(s + 1) * P), traj;
+        out.status[s] = simulate_sample(pb, theta, traj);
+        if (out.status[s] != 0) continue;
+        const size_t W = static_cast<size_t>(NUM_COMPARTMENTS) * n;
+        double* dst = &series[static_cast<size_t>(s) * 6 * Tp * n];
+        const int comps[3] = {9, 10, 8};
+        for (int ser = 0; ser < 3; ++ser) {
+            std::vector<double> prev(n);
+            const int first = pos_idx.empty() ? 0 : pos_idx[0];
+            for (int a = 0; a < n; ++a)
+                prev[a] = first > 0 ? traj[(first - 1) * W + comps[ser] * n + a] : pb.initial_state[comps[ser] * n + a];
+            for (int t = 0; t < Tp; ++t) {
+                const double* row = &traj[pos_idx[t] * W + comps[ser] * n];
+                for (int a = 0; a < n; ++a) {
+                    const double daily = std::max(0.0, row[a] - prev[a]);
+                    prev[a] = row[a];
+                    dst[(static_cast<size_t>(ser) * Tp + t) * n + a] = daily;
+                    dst[(static_cast<size_t>(ser + 3) * Tp + t) * n + a] =
+                        t == 0 ? daily : dst[(static_cast<size_t>(ser + 3) * Tp + t - 1) * n + a] + daily;
+                }
+            }
+        }
+        for (int k = 0; k < T; ++k) {
+            double tot = 0.0;
+            for (int a = 0; a < n; ++a) tot += traj[k * W + a];
+            sero[static_cast<size_t>(s) * T + k] = (total_pop - tot) / total_pop;
+        }
+    }
+    out.ppc.assign(static_cast<size_t>(6) * np * Tp * n, std::numeric_limits<double>::quiet_NaN());
+    out.sero.assign(static_cast<size_t>(np) * T, std::numeric_limits<double>::quiet_NaN());
+    for (int s = 0; s < S; ++s) out.n_valid += out.status[s] == 0;
+    if (out.n_valid == 0) return out;
+    std::vector<double> v;
+    for (int ser = 0; ser < 6; ++ser)
+        for (int t = 0; t < Tp; ++t)
+            for (int a = 0; a < n; ++a) {
+                v.clear();
+                for (int s = 0; s < S; ++s)
+                    if (out.status[s] == 0) v.push_back(series[static_cast<size_t>(s) * 6 * Tp * n + (static_cast<size_t>(ser) * Tp + t) * n + a]);
+                std::sort(v.begin(), v.end());
+                for (int p = 0; p < np; ++p)
+                    out.ppc[((static_cast<size_t>(ser) * np + p) * Tp + t) * n + a] = sorted_quantile(v, probs[p]);
+            }
+    for (int k = 0; k < T; ++k) {
+        v.clear();
+        for (int s = 0; s < S; ++s)
+            if (out.status[s] == 0) v.push_back(sero[static_cast<size_t>(s) * T + k]);
+        std::sort(v.begin(), v.end());
+        for (int p = 0; p < np; ++p) out.sero[static_cast<size_t>(p) * T + k] = sorted_quantile(v, probs[p]);
+    }
+    return out;
+}
+
+// -----------------------------------------------------------------------------
 // SimulationCache::computeHash  (src/sir_age_structured/caching/SimulationCache.cpp:12-19,35-52)
 // -----------------------------------------------------------------------------
 inline uint64_t mix_hash(uint64_t k) {
