@@ -58,19 +58,31 @@ __global__ __launch_bounds__(WAVE) void ensemble_series_kernel(const EnsembleArg
     // cum rows are D, CumH, CumICU
     const int comp_of[3] = {1, 2, 0};
     double run[3] = {0.0, 0.0, 0.0};
-    for (int t = 0; t < a.Tp; ++t) {
-        const size_t k = (size_t)(a.runup_offset + t);
+    // the running sums are a dependent chain, the loads are not: 8 days are requested at a time
+    constexpr int DAYS = 8;
+    for (int t0 = 0; t0 < a.Tp; t0 += DAYS) {
+        double inc[DAYS][3];
 #pragma unroll
-        for (int ser = 0; ser < 3; ++ser) {
-            double daily = inf, cumulative = inf;
-            if (ok) {
-                const double inc = a.cum[(k * 3 + comp_of[ser]) * a.cum_stride + col];
-                daily = (0.0 < inc) ? inc : 0.0;                 // std::max(0.0, cur - prev)
-                run[ser] = (t == 0) ? daily : run[ser] + daily;  // row(t) = row(t-1) + daily.row(t)
-                cumulative = run[ser];
+        for (int d = 0; d < DAYS; ++d) {
+            const size_t k = (size_t)(a.runup_offset + (t0 + d < a.Tp ? t0 + d : a.Tp - 1));
+#pragma unroll
+            for (int ser = 0; ser < 3; ++ser) inc[d][ser] = ok ? a.cum[(k * 3 + comp_of[ser]) * a.cum_stride + col] : 0.0;
+        }
+#pragma unroll
+        for (int d = 0; d < DAYS; ++d) {
+            const int t = t0 + d;
+            if (t >= a.Tp) break;
+#pragma unroll
+            for (int ser = 0; ser < 3; ++ser) {
+                double daily = inf, cumulative = inf;
+                if (ok) {
+                    daily = (0.0 < inc[d][ser]) ? inc[d][ser] : 0.0;  // std::max(0.0, cur - prev)
+                    run[ser] = (t == 0) ? daily : run[ser] + daily;   // row(t) = row(t-1) + daily.row(t)
+                    cumulative = run[ser];
+                }
+                a.vals[(((size_t)ser * a.Tp + t) * a.n + age) * seg_stride + s] = daily;
+                a.vals[(((size_t)(ser + 3) * a.Tp + t) * a.n + age) * seg_stride + s] = cumulative;
             }
-            a.vals[(((size_t)ser * a.Tp + t) * a.n + age) * seg_stride + s] = daily;
-            a.vals[(((size_t)(ser + 3) * a.Tp + t) * a.n + age) * seg_stride + s] = cumulative;
         }
     }
     if (a.traj != nullptr && a.sero_out != nullptr && age == 0) {

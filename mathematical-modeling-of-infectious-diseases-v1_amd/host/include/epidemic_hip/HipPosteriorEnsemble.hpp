@@ -1,0 +1,69 @@
+// host/include/epidemic_hip/HipPosteriorEnsemble.hpp
+//
+// Post-calibration ensemble on the device: the second consumer of the integrator
+// (SURVEY 8f rank 1).  Mirrors, for this path only,
+//   ResultAggregator::aggregatePosteriorPredictives   src/model/ResultAggregator.cpp:174-396
+//     (result type PosteriorPredictiveData, include/model/AnalysisTypes.hpp:44-62)
+//   the seroprevalence aggregation of PostCalibrationAnalyser::analyzeMCMCRunsInBatches
+//     src/model/PostCalibrationAnalyser.cpp:209-246,303-343 (AggregatedStats per time point)
+// Every selected sample is simulated from the GIVEN initial state, as
+// SimulationRunner::runSimulation does (src/model/SimulationRunner.cpp:24-104), in ONE device
+// launch; the per-time quantiles come from an exact sort on the device.  Differences from the
+// reference, by design: the incidence quantiles use the exact-sort rule of
+// PostCalibrationAnalyser.cpp:316-326 instead of Boost.Accumulators' order-dependent P^2 estimate;
+// Rt trajectories (dense eigenvalue problem per sample and time) are not on this path.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "epidemic_hip/HipSEPAIHRD.hpp"
+
+namespace epidemic {
+
+struct PosteriorPredictiveData {
+    std::vector<double> time_points;  // the output times >= 0
+    struct IncidenceData {
+        Eigen::MatrixXd median, lower_90, upper_90, lower_95, upper_95;  // T_pos x n_age
+        Eigen::MatrixXd observed;
+    };
+    IncidenceData daily_hospitalizations, daily_icu_admissions, daily_deaths;
+    IncidenceData cumulative_hospitalizations, cumulative_icu_admissions, cumulative_deaths;
+    int samples_used = 0;  // simulations that were valid (build-side addition)
+};
+
+using AggregatedStats = std::map<std::string, double>;  // "median", "q025", "q975", "q05", "q95"
+
+class HipPosteriorEnsemble {
+public:
+    HipPosteriorEnsemble(HipSEPAIHRDParameterManager& parameterManager, const CalibrationData& observed_data,
+                         const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+                         std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error = 1.0e-6,
+                         double rel_error = 1.0e-6, int device = -1, bool fma_arithmetic = false);
+
+    // sample selection as ResultAggregator.cpp:246-266: num_samples_for_ppc draws WITH replacement from
+    // mt19937(random_seed) + uniform_int_distribution when 0 < num < size, else every sample in order.
+    // random_seed = 0 means std::random_device in the reference; here it is rejected (reproducibility).
+    static std::vector<int> selectSamples(size_t n_samples, int num_samples_for_ppc, unsigned int random_seed);
+
+    PosteriorPredictiveData aggregatePosteriorPredictives(const std::vector<Eigen::VectorXd>& param_samples,
+                                                          int num_samples_for_ppc, unsigned int random_seed);
+
+    // samples burn_in, burn_in + thinning, ... (PostCalibrationAnalyser.cpp:209); one entry per output time
+    std::map<double, AggregatedStats> aggregateSeroprevalence(const std::vector<Eigen::VectorXd>& param_samples,
+                                                              int burn_in, int thinning);
+
+private:
+    void run(const std::vector<double>& thetas, int S, bool want_sero);
+    HipSEPAIHRDParameterManager& pm_;
+    const CalibrationData& data_;
+    std::vector<double> time_points_;
+    SimulationCache cache_;
+    std::unique_ptr<HipSEPAIHRDObjectiveFunction> objective_;
+    int n_ = 0, t_pos_ = 0;
+    std::vector<double> ppc_, sero_;  // [6][5][T_pos][n], [5][T]
+    int n_valid_ = 0;
+};
+
+}  // namespace epidemic

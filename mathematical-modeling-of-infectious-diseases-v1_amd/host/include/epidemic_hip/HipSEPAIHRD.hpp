@@ -135,6 +135,9 @@ public:
     // per-chain step counters of the last calculateBatch (diagnostics)
     const std::vector<int32_t>& lastAccepted() const { return n_acc_; }
     const std::vector<int32_t>& lastRejected() const { return n_rej_; }
+    // build-side accessors for other device callers of the same problem (HipPosteriorEnsemble)
+    sepaihrd_ctx* deviceContext() const { return ctx_; }
+    void syncDeviceConstraintMode() const { syncConstraintMode(); }
 private:
     void syncConstraintMode() const;
     HipSEPAIHRDParameterManager& pm_;

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
 #include "sepaihrd_hip.h"
 
@@ -96,6 +97,63 @@ void* host_objective_create(const sepaihrd_problem* pb, const char* names, const
 }
 
 void host_objective_destroy(void* hv) { delete static_cast<HostHandle*>(hv); }
+
+// HipPosteriorEnsemble over the handle's parameter manager / data.  samples: n_samples x P.
+// ppc: [6 series][5: lower_95, lower_90, median, upper_90, upper_95][T_pos][n]; selected: capacity
+// max(n_samples, num_for_ppc) indices actually simulated; sero (nullable): [5: q025,q05,median,q95,q975][T]
+// over samples burn_in, burn_in + thinning, ...
+int host_ensemble(void* hv, const sepaihrd_problem* pb, int device, const double* samples, int n_samples,
+                  int num_for_ppc, uint32_t seed, double* ppc, int32_t* selected, int32_t* n_selected,
+                  int32_t* samples_used, int burn_in, int thinning, double* sero) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int n = pb->n_age;
+        const size_t P = h->pm->getParameterCount();
+        std::shared_ptr<IOdeSolverStrategy> solver;
+        if (pb->solver == SEPAIHRD_SOLVER_CASH_KARP54) solver = std::make_shared<CashKarpSolverStrategy>();
+        else solver = std::make_shared<Dopri5SolverStrategy>();
+        const std::vector<double> times(pb->times, pb->times + pb->n_times);
+        HipPosteriorEnsemble ens(*h->pm, *h->data, times, vec(pb->initial_state, 11 * n), solver, pb->abs_err, pb->rel_err,
+                                 device, pb->arith == SEPAIHRD_ARITH_FMA);
+        std::vector<Eigen::VectorXd> ps(static_cast<size_t>(n_samples), Eigen::VectorXd(static_cast<Eigen::Index>(P)));
+        for (int s = 0; s < n_samples; ++s)
+            for (size_t i = 0; i < P; ++i) ps[static_cast<size_t>(s)][static_cast<Eigen::Index>(i)] = samples[static_cast<size_t>(s) * P + i];
+        const std::vector<int> sel = HipPosteriorEnsemble::selectSamples(ps.size(), num_for_ppc, seed);
+        for (size_t i = 0; i < sel.size(); ++i) selected[i] = sel[i];
+        *n_selected = static_cast<int32_t>(sel.size());
+        const PosteriorPredictiveData d = ens.aggregatePosteriorPredictives(ps, num_for_ppc, seed);
+        *samples_used = d.samples_used;
+        const PosteriorPredictiveData::IncidenceData* series[6] = {&d.daily_hospitalizations, &d.daily_icu_admissions,
+                                                                   &d.daily_deaths, &d.cumulative_hospitalizations,
+                                                                   &d.cumulative_icu_admissions, &d.cumulative_deaths};
+        const size_t Tp = d.time_points.size();
+        for (int ser = 0; ser < 6; ++ser) {
+            const Eigen::MatrixXd* m[5] = {&series[ser]->lower_95, &series[ser]->lower_90, &series[ser]->median,
+                                           &series[ser]->upper_90, &series[ser]->upper_95};
+            for (int q = 0; q < 5; ++q)
+                for (size_t t = 0; t < Tp; ++t)
+                    for (int a = 0; a < n; ++a)
+                        ppc[((static_cast<size_t>(ser) * 5 + q) * Tp + t) * n + a] =
+                            (*m[q])(static_cast<Eigen::Index>(t), a);
+        }
+        if (sero) {
+            const auto agg = ens.aggregateSeroprevalence(ps, burn_in, thinning);
+            const char* keys[5] = {"q025", "q05", "median", "q95", "q975"};
+            size_t k = 0;
+            for (double t : times) {
+                const auto it = agg.find(t);
+                for (int q = 0; q < 5; ++q)
+                    sero[static_cast<size_t>(q) * times.size() + k] =
+                        it == agg.end() ? std::numeric_limits<double>::quiet_NaN() : it->second.at(keys[q]);
+                ++k;
+            }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
 
 // returns 0 ok, 1 = exception thrown by calculate() (message in host_last_error)
 int host_objective_calculate(void* hv, const double* theta, double* value) {

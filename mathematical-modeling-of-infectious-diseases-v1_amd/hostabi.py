@@ -39,6 +39,8 @@ def load_library() -> C.CDLL:
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
+                                  vp, vp, vp, vp, C.c_int, C.c_int, vp]
     _lib = lib
     return lib
 
@@ -66,6 +68,26 @@ class HostObjective:
                 self.h = None
         except Exception:
             pass
+
+    def posterior_ensemble(self, samples, num_for_ppc: int, seed: int, burn_in: int = 0, thinning: int = 1,
+                           want_sero: bool = True, device: int = -1) -> dict:
+        """HipPosteriorEnsemble::aggregatePosteriorPredictives (+ aggregateSeroprevalence) over this handle's
+        parameter manager and data.  ppc: [6][5: lower_95, lower_90, median, upper_90, upper_95][T_pos][n]."""
+        ps = np.ascontiguousarray(np.atleast_2d(samples), dtype=np.float64)
+        keep: list = []
+        st = hipabi.build_problem_struct(self.pb, keep)
+        n, T = self.pb.n, self.pb.n_times
+        Tp = int(np.sum(np.asarray(self.pb.times) >= 0.0))
+        ppc = np.empty((6, 5, Tp, n))
+        sel = np.empty(max(ps.shape[0], num_for_ppc, 1), dtype=np.int32)
+        nsel, used = C.c_int32(0), C.c_int32(0)
+        sero = np.empty((5, T)) if want_sero else None
+        rc = self.lib.host_ensemble(self.h, C.byref(st), device, ps.ctypes.data, ps.shape[0], num_for_ppc, seed,
+                                    ppc.ctypes.data, sel.ctypes.data, C.byref(nsel), C.byref(used), burn_in, thinning,
+                                    sero.ctypes.data if want_sero else None)
+        if rc != 0:
+            raise RuntimeError("host_ensemble: " + self.lib.host_last_error().decode())
+        return {"ppc": ppc, "selected": sel[:nsel.value].copy(), "samples_used": used.value, "sero": sero}
 
     def calculate(self, theta) -> float:
         th = np.ascontiguousarray(theta, dtype=np.float64)

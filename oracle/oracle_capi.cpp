@@ -224,6 +224,12 @@ int oracle_ensemble(void* hv, const double* theta, int S, const double* probs, i
     return r.Tp;
 }
 
+int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t* out) {
+    const std::vector<int> sel = oracle::select_ppc_samples(static_cast<size_t>(n_samples), num_for_ppc, seed);
+    std::copy(sel.begin(), sel.end(), out);
+    return static_cast<int>(sel.size());
+}
+
 int oracle_num_threads(void) {
 #if defined(_OPENMP)
     return omp_get_max_threads();

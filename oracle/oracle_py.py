@@ -69,6 +69,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_mh.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_ppc_select.argtypes = [C.c_int, C.c_int, C.c_uint32, vp]
     lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
         _lib = lib
@@ -221,6 +222,12 @@ class Oracle:
         return {"best": best, "best_value": best_value.value, "accepted": accepted.value,
                 "final_scale": final_scale.value, "accept_trace": trace[:iterations - 1],
                 "samples": samples[:ns], "sample_values": values[:ns], "final_cov": cov}
+
+
+def ppc_select(n_samples: int, num_for_ppc: int, seed: int) -> np.ndarray:
+    out = np.empty(max(n_samples, num_for_ppc, 1), dtype=np.int32)
+    k = load().oracle_ppc_select(n_samples, num_for_ppc, seed, out.ctypes.data)
+    return out[:k].copy()
 
 
 def poisson_loglik(sim, obs) -> float:

@@ -779,6 +779,20 @@ inline int simulate_sample(const Problem& pb, const std::vector<double>& theta, 
     return 0;
 }
 
+// sample selection of ResultAggregator::aggregatePosteriorPredictives (ResultAggregator.cpp:246-266)
+inline std::vector<int> select_ppc_samples(size_t n_samples, int num_samples_for_ppc, unsigned int seed) {
+    std::vector<int> sel;
+    if (num_samples_for_ppc > 0 && static_cast<size_t>(num_samples_for_ppc) < n_samples) {
+        std::mt19937 gen;
+        gen.seed(seed);
+        std::uniform_int_distribution<> distrib(0, static_cast<int>(n_samples) - 1);
+        for (int i = 0; i < num_samples_for_ppc; ++i) sel.push_back(distrib(gen));
+    } else {
+        for (size_t i = 0; i < n_samples; ++i) sel.push_back(static_cast<int>(i));
+    }
+    return sel;
+}
+
 inline double sorted_quantile(const std::vector<double>& v, double q) {
     const double pos = q * (v.size() - 1);
     const size_t idx = static_cast<size_t>(pos);

@@ -113,3 +113,34 @@ def test_hip_ensemble_argument_checks(mm, shipped):
         hip.ensemble_quantiles(theta, [0.5, 1.5])
     with pytest.raises(RuntimeError):
         hip.set_initial_state_mode(7)
+
+
+@pytest.mark.gpu
+def test_host_posterior_ensemble_mirror(mm, oracle_py, shipped):
+    """C++ HipPosteriorEnsemble (ResultAggregator::aggregatePosteriorPredictives shape): same sample
+    selection as the reference's mt19937 + uniform_int_distribution, same numbers as the oracle."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT)
+    n_samples, num_for_ppc, seed = 120, 40, 2024
+    samples = _draws(oracle_py, pb, n_samples, seed0=77)
+    host = mm.HostObjective(pb)
+    got = host.posterior_ensemble(samples, num_for_ppc, seed, burn_in=20, thinning=3)
+    sel = oracle_py.ppc_select(n_samples, num_for_ppc, seed)
+    assert np.array_equal(got["selected"], sel) and len(sel) == num_for_ppc
+    orc = oracle_py.Oracle(pb)
+    ref = orc.ensemble_quantiles(samples[sel], PROBS)
+    assert got["samples_used"] == ref["n_valid"] == num_for_ppc
+    np.testing.assert_allclose(got["ppc"], ref["ppc"], rtol=1e-9, atol=1e-9)
+    ref_sero = orc.ensemble_quantiles(samples[20::3], PROBS)["sero"]
+    np.testing.assert_allclose(got["sero"], ref_sero, rtol=1e-9, atol=1e-12)
+    # num_for_ppc >= size: every sample once, in order (ResultAggregator.cpp:263-266)
+    allsel = host.posterior_ensemble(samples[:10], 50, seed, want_sero=False)["selected"]
+    assert np.array_equal(allsel, np.arange(10))
+
+
+def test_ppc_sample_selection_rule(oracle_py):
+    sel = oracle_py.ppc_select(1000, 25, 12345)
+    assert sel.shape == (25,) and sel.min() >= 0 and sel.max() < 1000
+    assert np.array_equal(sel, oracle_py.ppc_select(1000, 25, 12345))
+    assert not np.array_equal(sel, oracle_py.ppc_select(1000, 25, 12346))
+    assert np.array_equal(oracle_py.ppc_select(7, 0, 1), np.arange(7))
+    assert np.array_equal(oracle_py.ppc_select(7, 7, 1), np.arange(7))
