@@ -3,6 +3,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "epidemic_hip/BatchedHillClimbing.hpp"
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
 #include "sepaihrd_hip.h"
@@ -250,6 +251,41 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
             if (sample_values)
                 for (int s = 0; s < ns; ++s) sample_values[static_cast<size_t>(c) * ns + s] = r.sampleObjectiveValues[static_cast<size_t>(s)];
         }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// BatchedHillClimbingOptimizer in the clamp mode ModelCalibrator sets for phase 1
+// (ModelCalibrator.cpp:62-66).  use_scalar_interface hides calculateBatch from the optimizer, so that
+// every objective value comes from IObjectiveFunction::calculate (one launch per value).
+int host_hc_run(void* hv, const double* x0, uint32_t seed, int threads, int iterations, int cloud_size_multiplier,
+                int use_scalar_interface, double* best, double* best_value, double* final_cov, double* trace,
+                long* evaluations, long* launches) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        h->pm->setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);
+        BatchedHillClimbingOptimizer hc;
+        hc.configure({{"iterations", double(iterations)}, {"cloud_size_multiplier", double(cloud_size_multiplier)},
+                      {"threads", double(threads)}, {"seed", double(seed)}});
+        struct ScalarOnly : IObjectiveFunction {
+            IObjectiveFunction& inner;
+            explicit ScalarOnly(IObjectiveFunction& o) : inner(o) {}
+            double calculate(const Eigen::VectorXd& p) const override { return inner.calculate(p); }
+            const std::vector<std::string>& getParameterNames() const override { return inner.getParameterNames(); }
+        } scalar(*h->obj);
+        const OptimizationResult r = use_scalar_interface ? hc.optimize(vec(x0, P), scalar, *h->pm)
+                                                          : hc.optimize(vec(x0, P), *h->obj, *h->pm);
+        for (int i = 0; i < P; ++i) best[i] = r.bestParameters[i];
+        *best_value = r.bestObjectiveValue;
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) final_cov[static_cast<size_t>(a) * P + b] = r.finalCovariance(a, b);
+        if (trace) std::copy(hc.currentTrace().begin(), hc.currentTrace().end(), trace);
+        if (evaluations) *evaluations = hc.evaluations();
+        if (launches) *launches = hc.launches();
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

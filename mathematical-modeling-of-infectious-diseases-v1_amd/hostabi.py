@@ -39,6 +39,7 @@ def load_library() -> C.CDLL:
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
                                   vp, vp, vp, vp, C.c_int, C.c_int, vp]
     _lib = lib
@@ -68,6 +69,23 @@ class HostObjective:
                 self.h = None
         except Exception:
             pass
+
+    def hill_climbing(self, x0, seed: int, iterations: int, cloud_size_multiplier: int = 8, threads: int = 16,
+                      use_scalar_interface: bool = False) -> dict:
+        """BatchedHillClimbingOptimizer::optimize in OPTIMIZATION_CLAMP mode (calibration phase 1)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        best = np.empty(self.P)
+        cov = np.empty((self.P, self.P))
+        trace = np.empty(iterations)
+        bv = C.c_double(0.0)
+        ne, nl = C.c_long(0), C.c_long(0)
+        rc = self.lib.host_hc_run(self.h, x0.ctypes.data, seed, threads, iterations, cloud_size_multiplier,
+                                  int(use_scalar_interface), best.ctypes.data, C.byref(bv), cov.ctypes.data,
+                                  trace.ctypes.data, C.byref(ne), C.byref(nl))
+        if rc != 0:
+            raise RuntimeError("host_hc_run: " + self.lib.host_last_error().decode())
+        return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace,
+                "evaluations": ne.value, "launches": nl.value}
 
     def posterior_ensemble(self, samples, num_for_ppc: int, seed: int, burn_in: int = 0, thinning: int = 1,
                            want_sero: bool = True, device: int = -1) -> dict:

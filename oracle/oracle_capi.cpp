@@ -224,6 +224,31 @@ int oracle_ensemble(void* hv, const double* theta, int S, const double* probs, i
     return r.Tp;
 }
 
+int oracle_hc(void* hv, int iterations, int cloud_size_multiplier, int threads, const double* x0, uint32_t seed,
+              double* best, double* best_value, double* final_cov, double* trace, long* evaluations) {
+    auto* h = static_cast<Handle*>(hv);
+    const int P = static_cast<int>(h->pb.pm.names.size());
+    oracle::HCSettings cfg;
+    cfg.iterations = iterations; cfg.cloud_size_multiplier = cloud_size_multiplier; cfg.threads = threads;
+    oracle::ParameterManager pm = h->pb.pm;
+    pm.mode = oracle::OPTIMIZATION_CLAMP;  // ModelCalibrator.cpp:62-66
+    oracle::Problem pb = h->pb;
+    pb.pm.mode = oracle::OPTIMIZATION_CLAMP;
+    auto fn = [&](const std::vector<double>& p) {
+        oracle::EvalInfo info;
+        const double v = oracle::objective(pb, p, &info);
+        if (info.status >= 2) throw std::runtime_error("SimulationException");
+        return v;
+    };
+    const oracle::HCResult r = oracle::hill_climbing(cfg, std::vector<double>(x0, x0 + P), fn, pm, seed);
+    std::copy(r.best.begin(), r.best.end(), best);
+    *best_value = r.best_value;
+    std::copy(r.final_cov.begin(), r.final_cov.end(), final_cov);
+    if (trace) std::copy(r.current_trace.begin(), r.current_trace.end(), trace);
+    if (evaluations) *evaluations = r.evaluations;
+    return 0;
+}
+
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t* out) {
     const std::vector<int> sel = oracle::select_ppc_samples(static_cast<size_t>(n_samples), num_for_ppc, seed);
     std::copy(sel.begin(), sel.end(), out);

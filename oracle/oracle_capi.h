@@ -54,6 +54,9 @@ int oracle_mh(void *h, int iterations, int burn_in, int adaptation_period, int t
  * ppc [6][n_probs][Tp][n], sero [n_probs][T], status [S]; returns Tp, n_valid via pointers. */
 int oracle_ensemble(void *h, const double *theta, int S, const double *probs, int n_probs, double *ppc,
                     double *sero, int32_t *status, int32_t *n_valid, int nthreads);
+/* HillClimbingOptimizer restated (seeded, virtual threads).  trace: [iterations] current logL. */
+int oracle_hc(void *h, int iterations, int cloud_size_multiplier, int threads, const double *x0, uint32_t seed,
+              double *best, double *best_value, double *final_cov, double *trace, long *evaluations);
 /* returns the number of indices written (ResultAggregator.cpp:246-266) */
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t *out);
 int oracle_num_threads(void);

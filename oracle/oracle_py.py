@@ -69,6 +69,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_mh.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.oracle_ppc_select.argtypes = [C.c_int, C.c_int, C.c_uint32, vp]
     lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
@@ -167,6 +168,17 @@ class Oracle:
                                       sero.ctypes.data, status.ctypes.data, C.byref(nv), nthreads)
         assert tp == Tp
         return {"ppc": ppc, "sero": sero, "status": status, "n_valid": nv.value}
+
+    def hill_climbing(self, x0, seed: int, iterations: int, cloud_size_multiplier: int = 8, threads: int = 1) -> dict:
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        best = np.empty(self.P)
+        cov = np.empty((self.P, self.P))
+        trace = np.empty(iterations)
+        bv = C.c_double(0.0)
+        ne = C.c_long(0)
+        self.lib.oracle_hc(self.h, iterations, cloud_size_multiplier, threads, x0.ctypes.data, seed, best.ctypes.data,
+                           C.byref(bv), cov.ctypes.data, trace.ctypes.data, C.byref(ne))
+        return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace, "evaluations": ne.value}
 
     def calculate(self, theta) -> float:
         return float(self.eval_batch(theta, nthreads=1)["loglik"][0])

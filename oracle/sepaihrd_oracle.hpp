@@ -1102,4 +1102,204 @@ inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<dou
     return r;
 }
 
+// -----------------------------------------------------------------------------
+// HillClimbingOptimizer (src/sir_age_structured/optimizers/HillClimbingOptimizer.cpp:24-353):
+// candidate cloud (half correlated L z moves, half axis-aligned moves), winner, early accept,
+// backtracking + moving-anchor expansion line search (:39-112), rank-one covariance adaptation with
+// symmetrisation / jitter / diagonal floor (:279-307), Cholesky refresh every 10 iterations with
+// regularisation fallback (:310-341).  One objective call at a time, in the reference's order.
+// The reference seeds from std::random_device (:165-183); here the master generator takes a seed and
+// "threads" is a setting (virtual threads: thread t owns the candidates OpenMP's static schedule
+// would give it, with its own mt19937 and its own persistent normal_distribution, :186-214).
+// Dense products are restated element-wise (Eigen's evaluation order is not pinned by the reference).
+// -----------------------------------------------------------------------------
+struct HCSettings {
+    int iterations = 2000;
+    int cloud_size_multiplier = 8;
+    int threads = 1;
+};
+
+struct HCResult {
+    std::vector<double> best;
+    double best_value = 0.0;
+    std::vector<double> final_cov;          // P x P row-major
+    std::vector<double> current_trace;      // current_logL after every iteration
+    long evaluations = 0;
+};
+
+inline HCResult hill_climbing(const HCSettings& cfg, const std::vector<double>& x0, const Objective& objective_fn,
+                              ParameterManager& pm, uint32_t seed) {
+    const int P = static_cast<int>(x0.size());
+    HCResult r;
+    auto safe_eval = [&](const std::vector<double>& p) {  // :24-32
+        ++r.evaluations;
+        try {
+            double v = objective_fn(p);
+            if (std::isnan(v) || std::isinf(v)) return -1e18;
+            return v;
+        } catch (...) { return -1e18; }
+    };
+    auto sigma_of = [&](int i) { return pm.sigmas.at(pm.names[i]); };
+    auto add = [&](const std::vector<double>& a, const std::vector<double>& b, double sb) {
+        std::vector<double> o(P);
+        for (int i = 0; i < P; ++i) o[i] = a[i] + b[i] * sb;
+        return o;
+    };
+    r.best = x0;
+    r.best_value = safe_eval(x0);
+    std::vector<double> cur = x0, prev = x0;
+    double cur_l = r.best_value;
+    std::vector<double> cov(static_cast<size_t>(P) * P, 0.0), L;
+    for (int i = 0; i < P; ++i) {  // :146-150
+        const double s = sigma_of(i);
+        cov[i * P + i] = (s > 0 ? s * s : 1e-4);
+    }
+    cholesky_lower(cov, P, L);  // :153
+    const int V = std::max(1, cfg.threads);
+    const int nc = std::max(4, V * std::max(1, cfg.cloud_size_multiplier));  // :163
+    std::mt19937 master(seed);
+    std::vector<std::mt19937> rngs(V);
+    std::vector<std::normal_distribution<double>> norms(V);
+    for (int t = 0; t < V; ++t) {  // :179-183
+        const uint32_t a = static_cast<uint32_t>(master()), b = static_cast<uint32_t>(master()),
+                       c = static_cast<uint32_t>(master()), d = static_cast<uint32_t>(master());
+        std::seed_seq sq{a, b, c, d};
+        rngs[t].seed(sq);
+        norms[t] = std::normal_distribution<double>(0.0, 1.0);
+    }
+    // static schedule: thread t owns a contiguous block, the first nc % V threads one more
+    std::vector<int> owner(nc);
+    {
+        const int q = nc / V, rem = nc % V;
+        int i = 0;
+        for (int t = 0; t < V; ++t)
+            for (int k = 0; k < q + (t < rem ? 1 : 0); ++k) owner[i++] = t;
+    }
+    auto line_search = [&](std::vector<double>& params, double& logL, const std::vector<double>& direction) {  // :39-112
+        const double shrinkage = 0.5, growth = 2.0;
+        const int max_backtrack = 10, max_expansion = 12;
+        double step = 1.0;
+        std::vector<double> improved = params;
+        double improved_l = logL;
+        bool found = false;
+        for (int i = 0; i < max_backtrack; ++i) {
+            const std::vector<double> cand = pm.applyConstraints(add(params, direction, step));
+            double sq = 0.0;
+            for (int k = 0; k < P; ++k) sq += (cand[k] - params[k]) * (cand[k] - params[k]);
+            if (sq < 1e-16) break;
+            const double l = safe_eval(cand);
+            if (l > improved_l) { improved = cand; improved_l = l; found = true; break; }
+            step *= shrinkage;
+        }
+        if (!found) return false;
+        std::vector<double> best = improved;
+        double best_l = improved_l;
+        std::vector<double> cur_step(P);
+        for (int k = 0; k < P; ++k) cur_step[k] = improved[k] - params[k];
+        for (int i = 0; i < max_expansion; ++i) {
+            for (int k = 0; k < P; ++k) cur_step[k] *= growth;
+            const std::vector<double> cand = pm.applyConstraints(add(best, cur_step, 1.0));
+            const double l = safe_eval(cand);
+            if (l > best_l) { best = cand; best_l = l; } else break;
+        }
+        params = best;
+        logL = best_l;
+        return true;
+    };
+    std::vector<std::vector<double>> cand(nc, std::vector<double>(P)), ccand(nc, std::vector<double>(P));
+    std::vector<double> scores(nc, -1e18), z(P);
+    for (int iter = 0; iter < cfg.iterations; ++iter) {
+        for (int i = 0; i < nc; ++i) {  // :192-214, per owner thread in index order
+            std::mt19937& g = rngs[owner[i]];
+            std::normal_distribution<double>& nd = norms[owner[i]];
+            if (i < nc / 2) {
+                for (int k = 0; k < P; ++k) z[k] = nd(g);
+                for (int a = 0; a < P; ++a) {
+                    double sum = 0.0;
+                    for (int b = 0; b <= a; ++b) sum += L[a * P + b] * z[b];
+                    cand[i][a] = sum;
+                }
+            } else {
+                std::uniform_int_distribution<int> param_dist(0, P - 1);
+                const int idx = param_dist(g);
+                const double sg = std::sqrt(cov[idx * P + idx]);
+                std::fill(cand[i].begin(), cand[i].end(), 0.0);
+                cand[i][idx] = sg * nd(g);
+            }
+        }
+        for (int i = 0; i < nc; ++i) {  // :222-228
+            ccand[i] = pm.applyConstraints(add(cur, cand[i], 1.0));
+            scores[i] = safe_eval(ccand[i]);
+        }
+        int best_idx = -1;
+        double best_val = -1e18;
+        for (int i = 0; i < nc; ++i)
+            if (scores[i] > best_val) { best_val = scores[i]; best_idx = i; }
+        bool moved = false;
+        if (best_idx != -1 && best_val > -1e18) {  // :241-262
+            const std::vector<double> best_point = ccand[best_idx];
+            std::vector<double> dir(P);
+            for (int k = 0; k < P; ++k) dir[k] = best_point[k] - cur[k];
+            if (best_val > cur_l) { cur = best_point; cur_l = best_val; moved = true; }
+            const bool ls = line_search(cur, cur_l, dir);
+            moved = moved || ls;
+        }
+        if (moved) {  // :265-308
+            if (cur_l > r.best_value) { r.best_value = cur_l; r.best = cur; }
+            std::vector<double> st(P);
+            double norm2 = 0.0;
+            for (int k = 0; k < P; ++k) { st[k] = cur[k] - prev[k]; norm2 += st[k] * st[k]; }
+            if (norm2 > 1e-14) {
+                const double alpha = 2.0 / (P + 2.0);
+                for (int a = 0; a < P; ++a)
+                    for (int b = 0; b < P; ++b) {
+                        double v = cov[a * P + b] * (1.0 - alpha);
+                        v += alpha * (st[a] * st[b]);
+                        cov[a * P + b] = v;
+                    }
+                std::vector<double> sym(cov.size());
+                for (int a = 0; a < P; ++a)
+                    for (int b = 0; b < P; ++b) sym[a * P + b] = 0.5 * (cov[a * P + b] + cov[b * P + a]);
+                cov = sym;
+                double tr = 0.0;
+                for (int a = 0; a < P; ++a) tr += cov[a * P + a];
+                const double jitter = 1e-8 * tr / P;
+                for (int a = 0; a < P; ++a) cov[a * P + a] += jitter;
+                for (int a = 0; a < P; ++a) {
+                    double mv = sigma_of(a);
+                    mv = (mv > 0 ? mv * mv * 0.01 : 1e-8);
+                    if (cov[a * P + a] < mv) cov[a * P + a] = mv;
+                }
+            }
+            prev = cur;
+        }
+        if (iter > 0 && iter % 10 == 0) {  // :313-341
+            std::vector<double> Ln;
+            if (cholesky_lower(cov, P, Ln)) {
+                L = Ln;
+            } else {
+                double tr = 0.0;
+                for (int a = 0; a < P; ++a) tr += cov[a * P + a];
+                double lambda = 1e-6 * tr / P;
+                bool regularized = false;
+                for (int attempt = 0; attempt < 5; ++attempt) {
+                    for (int a = 0; a < P; ++a) cov[a * P + a] += lambda;
+                    if (cholesky_lower(cov, P, Ln)) { L = Ln; regularized = true; break; }
+                    lambda *= 10.0;
+                }
+                if (!regularized) {
+                    L.assign(static_cast<size_t>(P) * P, 0.0);
+                    for (int a = 0; a < P; ++a) L[a * P + a] = std::sqrt(cov[a * P + a]);
+                    for (int a = 0; a < P; ++a)
+                        for (int b = 0; b < P; ++b)
+                            if (a != b) cov[a * P + b] = 0.0;
+                }
+            }
+        }
+        r.current_trace.push_back(cur_l);
+    }
+    r.final_cov = cov;
+    return r;
+}
+
 }  // namespace oracle

@@ -90,3 +90,23 @@ def test_multichain_equals_scalar_interface(mm, ref_fixture):
                                                  scalar_interface=True)
     assert np.array_equal(a["accept_trace"], b["accept_trace"])
     assert np.array_equal(a["samples"], b["samples"])
+
+
+def test_batched_hill_climbing_follows_the_serial_search(mm, oracle_py, shipped):
+    """BatchedHillClimbingOptimizer (cloud, backtracking and expansion each as ONE launch) walks the
+    path of the one-call-at-a-time HillClimbingOptimizer restatement in the oracle
+    (HillClimbingOptimizer.cpp:132-353), same seed and virtual threads."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=0)
+    iters, mult, threads, seed = 25, 4, 4, 99
+    ref = oracle_py.Oracle(pb).hill_climbing(pb.base_theta, seed, iters, mult, threads)
+    host = mm.HostObjective(pb)
+    got = host.hill_climbing(pb.base_theta, seed, iters, mult, threads)
+    np.testing.assert_allclose(got["trace"], ref["trace"], rtol=1e-10)
+    np.testing.assert_allclose(got["best"], ref["best"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["final_cov"], ref["final_cov"], rtol=1e-9, atol=1e-18)
+    assert got["best_value"] >= got["trace"][0] and np.all(np.diff(got["trace"]) >= 0)
+    # three launches per iteration at most (cloud, backtracking, expansion) + the initial value
+    assert got["launches"] <= 3 * iters + 1 and got["evaluations"] >= ref["evaluations"]
+    # the scalar interface (one launch per value, through calculate() and its cache) gives the same search
+    scalar = mm.HostObjective(pb).hill_climbing(pb.base_theta, seed, iters, mult, threads, use_scalar_interface=True)
+    assert np.array_equal(scalar["trace"], got["trace"]) and np.array_equal(scalar["best"], got["best"])
