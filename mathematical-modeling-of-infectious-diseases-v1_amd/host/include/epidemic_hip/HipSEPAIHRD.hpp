@@ -156,6 +156,14 @@ class MultiChainMetropolisHastings : public IOptimizationAlgorithm {
 public:
     void configure(const std::map<std::string, double>& settings) override;
     void setSeed(uint32_t seed) { seed_ = seed; }
+    // MetropolisHastingsSampler::setInitialCovariance (MetropolisHastingsSampler.cpp:52-63): every chain
+    // warm-starts from this covariance instead of diag(sigma^2) 2.38^2/P; a non-square matrix clears it
+    void setInitialCovariance(const Eigen::MatrixXd& cov) {
+        initial_cov_.clear();
+        if (cov.rows() > 0 && cov.rows() == cov.cols())
+            for (Eigen::Index a = 0; a < cov.rows(); ++a)
+                for (Eigen::Index b = 0; b < cov.cols(); ++b) initial_cov_.push_back(cov(a, b));
+    }
     // one chain through the scalar interface (drop-in for MetropolisHastingsSampler)
     OptimizationResult optimize(const Eigen::VectorXd& initialParameters, IObjectiveFunction& objectiveFunction,
                                 IParameterManager& parameterManager) override;
@@ -174,6 +182,7 @@ private:
     bool adapt_scale_ = true, store_samples_ = true;
     uint32_t seed_ = 1;
     std::vector<std::vector<unsigned char>> traces_;
+    std::vector<double> initial_cov_;  // row-major P x P, empty = none
 };
 
 }  // namespace epidemic

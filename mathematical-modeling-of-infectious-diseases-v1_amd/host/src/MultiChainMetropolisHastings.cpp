@@ -103,12 +103,16 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         ch.gen.seed(seed_ + static_cast<uint32_t>(c));
         ch.x.assign(initial.begin() + static_cast<size_t>(c) * P, initial.begin() + static_cast<size_t>(c + 1) * P);
         ch.prop.resize(static_cast<size_t>(P));
-        ch.cov.assign(PP, 0.0);
-        for (int i = 0; i < P; ++i) {  // :226-237
-            const double s = pm.getSigmaForParamIndex(i);
-            ch.cov[static_cast<size_t>(i) * P + i] = (s > 0 ? s * s : 1e-6);
+        if (initial_cov_.size() == PP) {  // warm start from phase 1 (:219-223): no 2.38^2/P scaling
+            ch.cov = initial_cov_;
+        } else {
+            ch.cov.assign(PP, 0.0);
+            for (int i = 0; i < P; ++i) {  // :226-237
+                const double s = pm.getSigmaForParamIndex(i);
+                ch.cov[static_cast<size_t>(i) * P + i] = (s > 0 ? s * s : 1e-6);
+            }
+            for (double& v : ch.cov) v *= scaling_factor;
         }
-        for (double& v : ch.cov) v *= scaling_factor;
         for (int i = 0; i < P; ++i) ch.cov[static_cast<size_t>(i) * P + i] += regularization_epsilon_;
         if (!cholesky(ch.cov, P, ch.chol)) {  // :240-246
             ch.chol.assign(PP, 0.0);

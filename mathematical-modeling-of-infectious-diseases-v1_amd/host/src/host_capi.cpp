@@ -4,6 +4,7 @@
 #include <sstream>
 
 #include "epidemic_hip/BatchedHillClimbing.hpp"
+#include "epidemic_hip/HipModelCalibrator.hpp"
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
 #include "sepaihrd_hip.h"
@@ -286,6 +287,50 @@ int host_hc_run(void* hv, const double* x0, uint32_t seed, int threads, int iter
         if (trace) std::copy(hc.currentTrace().begin(), hc.currentTrace().end(), trace);
         if (evaluations) *evaluations = hc.evaluations();
         if (launches) *launches = hc.launches();
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// HipModelCalibrator: two-phase calibration.  Per-chain outputs are chain-major; n_samples is per chain.
+int host_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
+                   int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed, int chains,
+                   double* best, double* best_value, double* initial_value, double* phase1_best_value,
+                   double* phase2_cov, unsigned char* accept_trace, double* samples, double* sample_values,
+                   double* mcmc_objective_values, int32_t* n_samples) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        h->pm->setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);  // mode at construction time
+        HipModelCalibrator cal(*h->pm, *h->obj);
+        cal.calibrate({{"iterations", double(hc_iterations)}, {"cloud_size_multiplier", double(cloud_size_multiplier)},
+                       {"threads", double(threads)}, {"seed", double(hc_seed)}},
+                      {{"mcmc_iterations", double(mh_iterations)}, {"burn_in", double(burn_in)},
+                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
+                       {"seed", double(mh_seed)}, {"store_samples", 1.0}},
+                      chains);
+        for (int i = 0; i < P; ++i) best[i] = cal.getBestParameterVector()[i];
+        *best_value = cal.getBestObjectiveValue();
+        if (initial_value) *initial_value = cal.getInitialObjectiveValue();
+        if (phase1_best_value) *phase1_best_value = cal.getPhase1Result().bestObjectiveValue;
+        if (phase2_cov)
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b) phase2_cov[static_cast<size_t>(a) * P + b] = cal.getPhase2Covariance()(a, b);
+        const auto& res = cal.getPhase2Results();
+        const int ns = static_cast<int>(res[0].samples.size());
+        if (n_samples) *n_samples = ns;
+        for (size_t c = 0; c < res.size(); ++c) {
+            if (accept_trace)
+                std::copy(cal.acceptTraces()[c].begin(), cal.acceptTraces()[c].end(), accept_trace + c * static_cast<size_t>(mh_iterations - 1));
+            for (int s = 0; s < ns; ++s) {
+                if (samples)
+                    for (int i = 0; i < P; ++i) samples[(c * ns + s) * P + i] = res[c].samples[static_cast<size_t>(s)][i];
+                if (sample_values) sample_values[c * ns + s] = res[c].sampleObjectiveValues[static_cast<size_t>(s)];
+            }
+        }
+        if (mcmc_objective_values) std::copy(cal.getMCMCObjectiveValues().begin(), cal.getMCMCObjectiveValues().end(), mcmc_objective_values);
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

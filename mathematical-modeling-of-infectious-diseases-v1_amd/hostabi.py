@@ -39,6 +39,8 @@ def load_library() -> C.CDLL:
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
                                   vp, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -86,6 +88,30 @@ class HostObjective:
             raise RuntimeError("host_hc_run: " + self.lib.host_last_error().decode())
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace,
                 "evaluations": ne.value, "launches": nl.value}
+
+    def calibrate(self, hc_seed: int, mh_seed: int, hc_iterations: int, mh_iterations: int, burn_in: int,
+                  cloud_size_multiplier: int = 8, threads: int = 16, adaptation_period: int = 100, thinning: int = 1,
+                  chains: int = 1) -> dict:
+        """HipModelCalibrator: HC (clamp) -> covariance conditioning -> `chains` MH chains (reflect)."""
+        cap = 1 + (mh_iterations - 1) // max(1, thinning)  # t = 0 and every thinning-th iteration after it
+        out = {"best": np.empty(self.P), "phase2_cov": np.empty((self.P, self.P)),
+               "accept_trace": np.empty((chains, mh_iterations - 1), dtype=np.uint8),
+               "samples": np.empty((chains, cap, self.P)), "sample_values": np.empty((chains, cap)),
+               "mcmc_objective_values": np.empty((chains, cap))}
+        bv, iv, p1 = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        ns = C.c_int32(0)
+        rc = self.lib.host_calibrate(self.h, hc_iterations, cloud_size_multiplier, threads, hc_seed, mh_iterations,
+                                     burn_in, adaptation_period, thinning, mh_seed, chains, out["best"].ctypes.data,
+                                     C.byref(bv), C.byref(iv), C.byref(p1), out["phase2_cov"].ctypes.data,
+                                     out["accept_trace"].ctypes.data, out["samples"].ctypes.data,
+                                     out["sample_values"].ctypes.data, out["mcmc_objective_values"].ctypes.data,
+                                     C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("host_calibrate: " + self.lib.host_last_error().decode())
+        n = ns.value
+        assert n == cap, (n, cap)
+        out.update(best_value=bv.value, initial_value=iv.value, phase1_best_value=p1.value, n_samples=n)
+        return out
 
     def posterior_ensemble(self, samples, num_for_ppc: int, seed: int, burn_in: int = 0, thinning: int = 1,
                            want_sero: bool = True, device: int = -1) -> dict:

@@ -249,6 +249,52 @@ int oracle_hc(void* hv, int iterations, int cloud_size_multiplier, int threads, 
     return 0;
 }
 
+int oracle_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
+                     int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed,
+                     const double* x0, double* best, double* best_value, double* initial_value,
+                     double* phase1_best_value, double* phase2_cov, unsigned char* accept_trace, double* samples,
+                     double* sample_values, double* mcmc_objective_values, int32_t* n_samples) {
+    auto* h = static_cast<Handle*>(hv);
+    oracle::Problem pb = h->pb;  // private copy: the calibrator switches the constraint mode
+    const int P = static_cast<int>(pb.pm.names.size());
+    oracle::HCSettings hc;
+    hc.iterations = hc_iterations; hc.cloud_size_multiplier = cloud_size_multiplier; hc.threads = threads;
+    oracle::MHSettings mh;
+    mh.iterations = mh_iterations; mh.burn_in = burn_in; mh.adaptation_period = adaptation_period;
+    mh.thinning = std::max(1, thinning);
+    oracle::Objective fn = [&pb](const std::vector<double>& p) {
+        oracle::EvalInfo info;
+        const double v = oracle::objective(pb, p, &info);
+        if (info.status >= 2) throw std::runtime_error("SimulationException");
+        return v;
+    };
+    const oracle::CalibrationResult r =
+        oracle::calibrate(hc, mh, std::vector<double>(x0, x0 + P), fn, pb.pm, hc_seed, mh_seed);
+    std::copy(r.best.begin(), r.best.end(), best);
+    *best_value = r.best_value;
+    if (initial_value) *initial_value = r.initial_value;
+    if (phase1_best_value) *phase1_best_value = r.phase1.best_value;
+    if (phase2_cov) std::copy(r.phase2_cov.begin(), r.phase2_cov.end(), phase2_cov);
+    if (accept_trace) std::copy(r.phase2.accept_trace.begin(), r.phase2.accept_trace.end(), accept_trace);
+    const int ns = static_cast<int>(r.phase2.samples.size());
+    if (n_samples) *n_samples = ns;
+    if (samples)
+        for (int s = 0; s < ns; ++s) std::copy(r.phase2.samples[s].begin(), r.phase2.samples[s].end(), samples + static_cast<size_t>(s) * P);
+    if (sample_values) std::copy(r.phase2.sample_values.begin(), r.phase2.sample_values.end(), sample_values);
+    if (mcmc_objective_values) std::copy(r.mcmc_objective_values.begin(), r.mcmc_objective_values.end(), mcmc_objective_values);
+    return 0;
+}
+
+int oracle_condition_covariance(void* hv, const double* cov, double* out) {
+    auto* h = static_cast<Handle*>(hv);
+    const oracle::ParameterManager& pm = h->pb.pm;
+    const int P = static_cast<int>(pm.names.size());
+    const std::vector<double> r = oracle::condition_phase1_covariance(
+        std::vector<double>(cov, cov + static_cast<size_t>(P) * P), P, [&](int i) { return pm.sigmas.at(pm.names[i]); });
+    std::copy(r.begin(), r.end(), out);
+    return 0;
+}
+
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t* out) {
     const std::vector<int> sel = oracle::select_ppc_samples(static_cast<size_t>(n_samples), num_for_ppc, seed);
     std::copy(sel.begin(), sel.end(), out);

@@ -57,6 +57,15 @@ int oracle_ensemble(void *h, const double *theta, int S, const double *probs, in
 /* HillClimbingOptimizer restated (seeded, virtual threads).  trace: [iterations] current logL. */
 int oracle_hc(void *h, int iterations, int cloud_size_multiplier, int threads, const double *x0, uint32_t seed,
               double *best, double *best_value, double *final_cov, double *trace, long *evaluations);
+/* ModelCalibrator restated: HC phase (clamp) -> covariance conditioning -> one MH chain (reflect).
+ * samples capacity: (mh_iterations / thinning + 1) x P.  All outputs nullable except best/best_value. */
+int oracle_calibrate(void *h, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
+                     int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed,
+                     const double *x0, double *best, double *best_value, double *initial_value,
+                     double *phase1_best_value, double *phase2_cov, unsigned char *accept_trace,
+                     double *samples, double *sample_values, double *mcmc_objective_values, int32_t *n_samples);
+/* ModelCalibrator.cpp:93-131 on a given covariance (row-major P x P) with the handle's sigmas */
+int oracle_condition_covariance(void *h, const double *cov, double *out);
 /* returns the number of indices written (ResultAggregator.cpp:246-266) */
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t *out);
 int oracle_num_threads(void);

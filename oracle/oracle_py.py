@@ -70,6 +70,9 @@ def load(path: str | None = None) -> C.CDLL:
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.oracle_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.oracle_condition_covariance.argtypes = [vp, vp, vp]
     lib.oracle_ppc_select.argtypes = [C.c_int, C.c_int, C.c_uint32, vp]
     lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
@@ -179,6 +182,34 @@ class Oracle:
         self.lib.oracle_hc(self.h, iterations, cloud_size_multiplier, threads, x0.ctypes.data, seed, best.ctypes.data,
                            C.byref(bv), cov.ctypes.data, trace.ctypes.data, C.byref(ne))
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace, "evaluations": ne.value}
+
+    def condition_covariance(self, cov) -> np.ndarray:
+        c = np.ascontiguousarray(cov, dtype=np.float64)
+        out = np.empty_like(c)
+        self.lib.oracle_condition_covariance(self.h, c.ctypes.data, out.ctypes.data)
+        return out
+
+    def calibrate(self, x0, hc_seed: int, mh_seed: int, hc_iterations: int, mh_iterations: int, burn_in: int,
+                  cloud_size_multiplier: int = 8, threads: int = 1, adaptation_period: int = 100,
+                  thinning: int = 1) -> dict:
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        cap = mh_iterations // max(1, thinning) + 1
+        out = {"best": np.empty(self.P), "phase2_cov": np.empty((self.P, self.P)),
+               "accept_trace": np.empty(mh_iterations - 1, dtype=np.uint8), "samples": np.empty((cap, self.P)),
+               "sample_values": np.empty(cap), "mcmc_objective_values": np.empty(cap)}
+        bv, iv, p1 = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        ns = C.c_int32(0)
+        self.lib.oracle_calibrate(self.h, hc_iterations, cloud_size_multiplier, threads, hc_seed, mh_iterations, burn_in,
+                                  adaptation_period, thinning, mh_seed, x0.ctypes.data, out["best"].ctypes.data,
+                                  C.byref(bv), C.byref(iv), C.byref(p1), out["phase2_cov"].ctypes.data,
+                                  out["accept_trace"].ctypes.data, out["samples"].ctypes.data,
+                                  out["sample_values"].ctypes.data, out["mcmc_objective_values"].ctypes.data,
+                                  C.byref(ns))
+        n = ns.value
+        out.update(best_value=bv.value, initial_value=iv.value, phase1_best_value=p1.value, n_samples=n)
+        for k in ("samples", "sample_values", "mcmc_objective_values"):
+            out[k] = out[k][:n]
+        return out
 
     def calculate(self, theta) -> float:
         return float(self.eval_batch(theta, nthreads=1)["loglik"][0])

@@ -924,6 +924,7 @@ struct MHSettings {
     int iterations = 10000, burn_in = 1000, adaptation_period = 100, thinning = 1;
     double regularization_epsilon = 1e-6, target_acceptance_rate = 0.234;
     bool adapt_scale = true;
+    std::vector<double> initial_cov;  // setInitialCovariance (:52-63): P x P row-major, empty = none
 };
 
 struct MHResult {
@@ -972,12 +973,16 @@ inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<dou
     MHResult r;
     std::vector<double> cur = x0;
     std::vector<double> cov(static_cast<size_t>(P) * P, 0.0);
-    for (int i = 0; i < P; ++i) {  // :226-233
-        double s = pm.sigmas.at(pm.names[i]);
-        cov[i * P + i] = (s > 0 ? s * s : 1e-6);
-    }
     const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
-    for (double& v : cov) v *= scaling_factor;
+    if (cfg.initial_cov.size() == cov.size()) {  // :219-223 warm start, no scaling
+        cov = cfg.initial_cov;
+    } else {
+        for (int i = 0; i < P; ++i) {  // :226-233
+            double s = pm.sigmas.at(pm.names[i]);
+            cov[i * P + i] = (s > 0 ? s * s : 1e-6);
+        }
+        for (double& v : cov) v *= scaling_factor;
+    }
     for (int i = 0; i < P; ++i) cov[i * P + i] += cfg.regularization_epsilon;  // :237
     std::vector<double> L;
     if (!cholesky_lower(cov, P, L)) {  // :240-246
@@ -1299,6 +1304,119 @@ inline HCResult hill_climbing(const HCSettings& cfg, const std::vector<double>& 
         r.current_trace.push_back(cur_l);
     }
     r.final_cov = cov;
+    return r;
+}
+
+// -----------------------------------------------------------------------------
+// ModelCalibrator (src/sir_age_structured/ModelCalibrator.cpp:13-159): initial objective value,
+// phase 1 in OPTIMIZATION_CLAMP mode, conditioning of the phase-1 covariance (symmetrise, eigenvalue
+// floor at (0.1 sigma_i)^2 with the i-th SMALLEST eigenvalue paired with parameter i as the reference
+// does, x4 inflation, trace jitter :93-131), phase 2 in MCMC_REFLECT mode warm-started from it,
+// objective value of every stored sample (:141-144).
+// The reference takes the eigen-decomposition from Eigen::SelfAdjointEigenSolver (not pinned); the
+// restatement uses a cyclic Jacobi iteration, eigenpairs sorted ascending like Eigen returns them.
+// -----------------------------------------------------------------------------
+inline void jacobi_eigen_sym(std::vector<double> A, int P, std::vector<double>& evals, std::vector<double>& evecs) {
+    std::vector<double> V(static_cast<size_t>(P) * P, 0.0);
+    for (int i = 0; i < P; ++i) V[i * P + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) (a == b ? diag : off) += A[a * P + b] * A[a * P + b];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < P - 1; ++p)
+            for (int q = p + 1; q < P; ++q) {
+                const double apq = A[p * P + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * P + q] - A[p * P + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < P; ++k) {  // columns p, q
+                    const double akp = A[k * P + p], akq = A[k * P + q];
+                    A[k * P + p] = c * akp - sn * akq;
+                    A[k * P + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < P; ++k) {  // rows p, q
+                    const double apk = A[p * P + k], aqk = A[q * P + k];
+                    A[p * P + k] = c * apk - sn * aqk;
+                    A[q * P + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < P; ++k) {
+                    const double vkp = V[k * P + p], vkq = V[k * P + q];
+                    V[k * P + p] = c * vkp - sn * vkq;
+                    V[k * P + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    std::vector<int> order(P);
+    for (int i = 0; i < P; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return A[a * P + a] < A[b * P + b]; });
+    evals.resize(P);
+    evecs.assign(static_cast<size_t>(P) * P, 0.0);
+    for (int k = 0; k < P; ++k) {
+        evals[k] = A[order[k] * P + order[k]];
+        for (int a = 0; a < P; ++a) evecs[a * P + k] = V[a * P + order[k]];
+    }
+}
+
+inline std::vector<double> condition_phase1_covariance(const std::vector<double>& cov_in, int P,
+                                                       const std::function<double(int)>& sigma_of) {
+    std::vector<double> cov(cov_in.size());
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b < P; ++b) cov[a * P + b] = 0.5 * (cov_in[a * P + b] + cov_in[b * P + a]);  // :100
+    std::vector<double> evals, evecs;
+    jacobi_eigen_sym(cov, P, evals, evecs);
+    for (int i = 0; i < P; ++i) {  // :107-111
+        const double min_var = std::pow(sigma_of(i) * 0.1, 2);
+        evals[i] = std::max(evals[i], min_var);
+    }
+    std::vector<double> ql(cov.size()), out(cov.size());
+    for (int a = 0; a < P; ++a)
+        for (int k = 0; k < P; ++k) ql[a * P + k] = evecs[a * P + k] * evals[k];
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b < P; ++b) {  // Q L' Q^T (:114)
+            double sum = 0.0;
+            for (int k = 0; k < P; ++k) sum += ql[a * P + k] * evecs[b * P + k];
+            out[a * P + b] = sum * 4.0;  // :117
+        }
+    double tr = 0.0;
+    for (int a = 0; a < P; ++a) tr += out[a * P + a];
+    const double eps = 1e-8 * tr / P;  // :120-121
+    for (int a = 0; a < P; ++a) out[a * P + a] += eps;
+    return out;
+}
+
+struct CalibrationResult {
+    double initial_value = 0.0;
+    HCResult phase1;
+    MHResult phase2;
+    std::vector<double> phase2_cov;  // conditioned covariance handed to the sampler
+    std::vector<double> best;
+    double best_value = 0.0;
+    std::vector<double> mcmc_objective_values;
+};
+
+// objective_fn must evaluate through the SAME ParameterManager object `pm` (its mode is switched)
+inline CalibrationResult calibrate(const HCSettings& hc_cfg, MHSettings mh_cfg, const std::vector<double>& x0,
+                                   const Objective& objective_fn, ParameterManager& pm, uint32_t hc_seed,
+                                   uint32_t mh_seed) {
+    const int P = static_cast<int>(x0.size());
+    CalibrationResult r;
+    r.best = x0;
+    r.best_value = objective_fn(x0);  // :36-45
+    r.initial_value = r.best_value;
+    if (std::isnan(r.best_value) || std::isinf(r.best_value)) r.best_value = -std::numeric_limits<double>::infinity();
+    pm.mode = OPTIMIZATION_CLAMP;  // :62-66
+    r.phase1 = hill_climbing(hc_cfg, r.best, objective_fn, pm, hc_seed);
+    if (r.phase1.best_value > r.best_value) { r.best_value = r.phase1.best_value; r.best = r.phase1.best; }
+    pm.mode = MCMC_REFLECT;  // :85-89
+    if (!r.phase1.final_cov.empty()) {
+        r.phase2_cov = condition_phase1_covariance(r.phase1.final_cov, P, [&](int i) { return pm.sigmas.at(pm.names[i]); });
+        mh_cfg.initial_cov = r.phase2_cov;
+    }
+    r.phase2 = metropolis_hastings(mh_cfg, r.best, objective_fn, pm, mh_seed);
+    if (r.phase2.best_value > r.best_value) { r.best_value = r.phase2.best_value; r.best = r.phase2.best; }
+    for (const auto& smp : r.phase2.samples) r.mcmc_objective_values.push_back(objective_fn(smp));  // :141-144
     return r;
 }
 

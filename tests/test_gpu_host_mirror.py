@@ -110,3 +110,26 @@ def test_batched_hill_climbing_follows_the_serial_search(mm, oracle_py, shipped)
     # the scalar interface (one launch per value, through calculate() and its cache) gives the same search
     scalar = mm.HostObjective(pb).hill_climbing(pb.base_theta, seed, iters, mult, threads, use_scalar_interface=True)
     assert np.array_equal(scalar["trace"], got["trace"]) and np.array_equal(scalar["best"], got["best"])
+
+
+def test_two_phase_calibration_follows_the_reference_flow(mm, oracle_py, shipped):
+    """HipModelCalibrator (ModelCalibrator.cpp:47-159): HC in clamp mode -> conditioned covariance ->
+    MH in reflect mode -> objective value of every stored sample; chain 0 of a 3-chain run walks the
+    path of the oracle's one-chain restatement."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=0)
+    kw = dict(hc_seed=5, mh_seed=6, hc_iterations=12, mh_iterations=300, burn_in=100, cloud_size_multiplier=2,
+              threads=4, adaptation_period=50, thinning=2)
+    ref = oracle_py.Oracle(pb).calibrate(pb.base_theta, **kw)
+    got = mm.HostObjective(pb).calibrate(chains=3, **kw)
+    np.testing.assert_allclose(got["initial_value"], ref["initial_value"], rtol=1e-10)
+    np.testing.assert_allclose(got["phase1_best_value"], ref["phase1_best_value"], rtol=1e-10)
+    np.testing.assert_allclose(got["phase2_cov"], ref["phase2_cov"], rtol=1e-8, atol=1e-20)
+    assert np.array_equal(got["accept_trace"][0], ref["accept_trace"])
+    assert 0 < ref["accept_trace"].sum() < len(ref["accept_trace"])
+    assert got["n_samples"] == ref["n_samples"]
+    np.testing.assert_allclose(got["samples"][0], ref["samples"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["sample_values"][0], ref["sample_values"], rtol=1e-10)
+    np.testing.assert_allclose(got["mcmc_objective_values"][0], ref["mcmc_objective_values"], rtol=1e-10)
+    # the other chains start from the same optimum with their own streams
+    assert not np.array_equal(got["accept_trace"][1], got["accept_trace"][0])
+    assert got["best_value"] >= ref["best_value"] * (1 - 1e-10)

@@ -190,3 +190,31 @@ def test_metropolis_hastings_restated(oracle_py, ref_fixture):
     r3 = orc.metropolis_hastings(ref_fixture.base_theta, seed=8, iterations=300, burn_in=100,
                                  adaptation_period=50, thinning=10)
     assert not np.array_equal(r1["accept_trace"], r3["accept_trace"])
+
+
+def test_phase1_covariance_conditioning_matches_symmetric_eigendecomposition(oracle_py, shipped):
+    """ModelCalibrator.cpp:93-131 restated with a Jacobi iteration == the same formula through LAPACK."""
+    P = shipped.n_params
+    rs = np.random.RandomState(3)
+    A = rs.randn(P, P) * 1e-3
+    cov = A @ A.T * 0.5 + np.diag(np.abs(rs.randn(P)) * 1e-8)
+    cov[0, 1] += 1e-9  # not exactly symmetric: the reference symmetrises first
+    got = oracle_py.Oracle(shipped).condition_covariance(cov)
+    w, Q = np.linalg.eigh(0.5 * (cov + cov.T))
+    w = np.maximum(w, (0.1 * shipped.sigma_array()) ** 2)  # i-th smallest eigenvalue <-> parameter i
+    ref = (Q * w) @ Q.T * 4.0
+    ref += 1e-8 * np.trace(ref) / P * np.eye(P)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.all(np.linalg.eigvalsh(got) > 0)
+
+
+def test_hill_climbing_restatement_properties(oracle_py, shipped):
+    orc = oracle_py.Oracle(shipped)
+    a = orc.hill_climbing(shipped.base_theta, 7, 12, cloud_size_multiplier=4, threads=2)
+    b = orc.hill_climbing(shipped.base_theta, 7, 12, cloud_size_multiplier=4, threads=2)
+    c = orc.hill_climbing(shipped.base_theta, 8, 12, cloud_size_multiplier=4, threads=2)
+    assert np.array_equal(a["trace"], b["trace"]) and not np.array_equal(a["trace"], c["trace"])
+    assert np.all(np.diff(a["trace"]) >= 0) and a["best_value"] == a["trace"][-1]
+    assert np.allclose(a["final_cov"], a["final_cov"].T, rtol=0, atol=0)
+    lo, hi, has = shipped.bounds_arrays()
+    assert np.all(a["best"][has.astype(bool)] >= lo[has.astype(bool)]) and np.all(a["best"][has.astype(bool)] <= hi[has.astype(bool)])
