@@ -221,6 +221,9 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
  * S <= 16384 (one sorted segment lives in LDS); larger ensembles: SEPAIHRD_E_UNSUPPORTED. */
 #define SEPAIHRD_INIT_FROM_THETA 0
 #define SEPAIHRD_INIT_FIXED 1
+/* the finite-difference objective's rule (SEPAIHRDGradientObjectiveFunction.cpp:55-99): always scale
+ * problem.initial_state by the multipliers, S by subtraction, invalid when the non-S total exceeds N or is negative */
+#define SEPAIHRD_INIT_MULTIPLIERS 2
 int sepaihrd_set_initial_state_mode(sepaihrd_ctx *ctx, int mode);
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, const double *probs,
                                 int n_probs, double *ppc_quantiles, double *sero_quantiles,

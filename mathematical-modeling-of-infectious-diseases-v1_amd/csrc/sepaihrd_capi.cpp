@@ -524,7 +524,7 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
 }
 
 int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
-    if (!ctx || (mode != SEPAIHRD_INIT_FROM_THETA && mode != SEPAIHRD_INIT_FIXED)) return SEPAIHRD_E_INVALID_ARG;
+    if (!ctx || mode < SEPAIHRD_INIT_FROM_THETA || mode > SEPAIHRD_INIT_MULTIPLIERS) return SEPAIHRD_E_INVALID_ARG;
     ctx->dp.init_mode = mode;
     return SEPAIHRD_OK;
 }

@@ -25,7 +25,7 @@ enum VecField { VF_A = 0, VF_H_INFEC, VF_P, VF_H, VF_ICU, VF_D_H, VF_D_ICU, VF_D
 struct DevProblem {
     int32_t n, lpc, T, n_obs, runup_offset, nb, nk, P, ns;
     int32_t constraint_mode, kappa_calibrated, max_attempts, obs_rows_match;
-    int32_t init_mode;  // 0: initial state derived from theta (objective), 1: problem.initial_state as given (ensemble runs)
+    int32_t init_mode;  // 0: from theta (objective), 1: problem.initial_state as given (ensemble), 2: multipliers always (FD gradient)
     double abs_tol, rel_tol, dt_hint, max_gap;
     const double* times;         // [T]
     // per output point k and lane (age): {obs_H, obs_ICU, obs_D, times[k+1]} -- 32 bytes, fetched by

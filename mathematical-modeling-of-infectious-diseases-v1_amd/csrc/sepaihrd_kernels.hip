@@ -439,10 +439,12 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     double x[NUM_COMP];
     SEP_UNROLL
     for (int c = 0; c < NUM_COMP; ++c) x[c] = pb.init_state[c * LPC + age];
-    if (pb.init_mode == 0) {
+    if (pb.init_mode != 1) {  // 1: problem.initial_state as given (SimulationRunner.cpp:24-104)
         const double runup_days = scalar_slot(SS_RUNUP_DAYS);
         const double seed_exposed = scalar_slot(SS_SEED_EXPOSED);
-        if (runup_days > 0 && seed_exposed > 0) {
+        // 2: the finite-difference objective always scales by the multipliers and also rejects a
+        //    negative non-S total (SEPAIHRDGradientObjectiveFunction.cpp:55-99)
+        if (pb.init_mode == 0 && runup_days > 0 && seed_exposed > 0) {
             x[1] = seed_exposed * pb.age_fraction[age];
             SEP_UNROLL
             for (int c = 2; c < NUM_COMP; ++c) x[c] = 0.0;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         double sum = 0;
         SEP_UNROLL
         for (int c = 1; c < NUM_POP_COMP; ++c) sum += x[c];
-        if (group_any<LPC>(sum > Ni, lane)) status = 1;
+        if (group_any<LPC>(sum > Ni || (pb.init_mode == 2 && sum < 0), lane)) status = 1;
         x[0] = Ni - sum;
     }
 

@@ -138,13 +138,48 @@ public:
     // build-side accessors for other device callers of the same problem (HipPosteriorEnsemble)
     sepaihrd_ctx* deviceContext() const { return ctx_; }
     void syncDeviceConstraintMode() const { syncConstraintMode(); }
-private:
+protected:
+    // builds the device context for this problem; multipliers_override (8 values) replaces the model's
+    // E0..D0 multipliers as the base values of the non-calibrated ones
+    static sepaihrd_ctx* createContext(const HipSEPAIHRDParameterManager& pm, const CalibrationData& data,
+                                       const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+                                       const std::shared_ptr<IOdeSolverStrategy>& solver_strategy, double abs_error,
+                                       double rel_error, int device, bool fma_arithmetic,
+                                       const double* multipliers_override);
     void syncConstraintMode() const;
     HipSEPAIHRDParameterManager& pm_;
     ISimulationCache& cache_;
     sepaihrd_ctx* ctx_ = nullptr;
     mutable int device_mode_ = -1;
     mutable std::vector<int32_t> n_acc_, n_rej_, status_;
+};
+
+// SEPAIHRDGradientObjectiveFunction (include/model/objectives/SEPAIHRDGradientObjectiveFunction.hpp,
+// src/model/objectives/SEPAIHRDGradientObjectiveFunction.cpp:15-171): forward differences, all P
+// perturbed simulations in ONE launch.  The perturbed runs follow that file's own rules, not
+// calculate()'s: fresh clamp-mode constraints, initial state ALWAYS scaled by the multipliers (read
+// unconstrained from the perturbed vector, 1.0 when not calibrated), invalid when the non-S total is
+// above N or negative (entry 0), likelihood over ALL output rows (a row count different from the
+// observations' makes every entry (lowest() - f) / eps, as in the reference).
+class HipSEPAIHRDGradientObjectiveFunction : public HipSEPAIHRDObjectiveFunction, public IGradientObjectiveFunction {
+public:
+    HipSEPAIHRDGradientObjectiveFunction(HipSEPAIHRDParameterManager& parameterManager, ISimulationCache& cache,
+                                         const CalibrationData& calibration_data, const std::vector<double>& time_points,
+                                         const Eigen::VectorXd& initial_state,
+                                         std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error = 1.0e-6,
+                                         double rel_error = 1.0e-6, int device = -1, bool fma_arithmetic = false);
+    ~HipSEPAIHRDGradientObjectiveFunction() override;
+    double epsilon_ = 1e-4;  // public in the reference too (:28)
+    double evaluate_with_gradient(const Eigen::VectorXd& params, Eigen::VectorXd& grad) const override;
+    double calculate(const Eigen::VectorXd& parameters) const override { return HipSEPAIHRDObjectiveFunction::calculate(parameters); }
+    const std::vector<std::string>& getParameterNames() const override { return HipSEPAIHRDObjectiveFunction::getParameterNames(); }
+private:
+    bool initialStateValid(const double* plus) const;
+    sepaihrd_ctx* grad_ctx_ = nullptr;
+    Eigen::VectorXd initial_state_;
+    size_t n_times_ = 0, n_obs_rows_ = 0;
+    double first_time_ = 0.0;
+    std::vector<int> mult_index_;  // parameter index of E0..D0 multiplier, -1 = not calibrated
 };
 
 // MetropolisHastingsSampler for many independent chains.  configure() takes the reference's

@@ -46,6 +46,13 @@ public:
     virtual void calculateBatch(const double* thetas, int B, double* out, int* status = nullptr) const = 0;
 };
 
+// include/model/interfaces/IGradientObjectiveFunction.hpp
+class IGradientObjectiveFunction : public virtual IObjectiveFunction {
+public:
+    virtual ~IGradientObjectiveFunction() = default;
+    virtual double evaluate_with_gradient(const Eigen::VectorXd& params, Eigen::VectorXd& grad) const = 0;
+};
+
 class IParameterManager {
 public:
     virtual ~IParameterManager() = default;

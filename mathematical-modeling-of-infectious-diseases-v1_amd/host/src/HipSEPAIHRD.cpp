@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "sepaihrd_hip.h"
 
@@ -276,6 +277,15 @@ HipSEPAIHRDObjectiveFunction::HipSEPAIHRDObjectiveFunction(
     std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error, double rel_error, int device,
     bool fma_arithmetic)
     : pm_(parameterManager), cache_(cache) {
+    ctx_ = createContext(pm_, data, time_points, initial_state, solver_strategy, abs_error, rel_error, device,
+                         fma_arithmetic, nullptr);
+    device_mode_ = pm_.getConstraintMode() == ConstraintMode::MCMC_REFLECT ? SEPAIHRD_CONSTRAINT_REFLECT : SEPAIHRD_CONSTRAINT_CLAMP;
+}
+
+sepaihrd_ctx* HipSEPAIHRDObjectiveFunction::createContext(
+    const HipSEPAIHRDParameterManager& pm_, const CalibrationData& data, const std::vector<double>& time_points,
+    const Eigen::VectorXd& initial_state, const std::shared_ptr<IOdeSolverStrategy>& solver_strategy, double abs_error,
+    double rel_error, int device, bool fma_arithmetic, const double* multipliers_override) {
     const char* W = "SEPAIHRDObjectiveFunction";
     const SEPAIHRDParameters& mp = pm_.modelParameters();
     const int n = static_cast<int>(mp.N.size());
@@ -304,6 +314,14 @@ HipSEPAIHRDObjectiveFunction::HipSEPAIHRDObjectiveFunction(
         lo[i] = pm_.getLowerBoundForParamIndex(static_cast<int>(i));
         hi[i] = pm_.getUpperBoundForParamIndex(static_cast<int>(i));
         has[i] = pm_.hasBounds(static_cast<int>(i)) ? 1 : 0;
+        // finite-difference context: the multipliers reach the initial state UNCONSTRAINED
+        // (SEPAIHRDGradientObjectiveFunction.cpp:59-83 reads them from params_plus)
+        const int32_t f = pm_.fieldCodes()[i];
+        if (multipliers_override && f >= SEPAIHRD_F_E0_MULT && f <= SEPAIHRD_F_D0_MULT) {
+            lo[i] = -std::numeric_limits<double>::infinity();
+            hi[i] = std::numeric_limits<double>::infinity();
+            has[i] = 1;
+        }
     }
 
     sepaihrd_problem pb;
@@ -333,14 +351,14 @@ HipSEPAIHRDObjectiveFunction::HipSEPAIHRDObjectiveFunction(
     pb.gamma_I = mp.gamma_I; pb.gamma_H = mp.gamma_H; pb.gamma_ICU = mp.gamma_ICU;
     const double mult[8] = {mp.E0_multiplier, mp.P0_multiplier, mp.A0_multiplier, mp.I0_multiplier,
                             mp.H0_multiplier, mp.ICU0_multiplier, mp.R0_multiplier, mp.D0_multiplier};
-    std::memcpy(pb.multipliers, mult, sizeof(mult));
+    std::memcpy(pb.multipliers, multipliers_override ? multipliers_override : mult, sizeof(mult));
     pb.runup_days = mp.runup_days; pb.seed_exposed = mp.seed_exposed;
     pb.abs_err = abs_error; pb.rel_err = rel_error; pb.dt_hint = 1.0;  // simulator built with dt = 1.0 (:113-114)
 
     char err[512] = {0};
-    ctx_ = sepaihrd_create(&pb, device, err, sizeof(err));
-    if (!ctx_) throw ModelException(W, std::string("sepaihrd_create failed: ") + err);
-    device_mode_ = pb.constraint_mode;
+    sepaihrd_ctx* ctx = sepaihrd_create(&pb, device, err, sizeof(err));
+    if (!ctx) throw ModelException(W, std::string("sepaihrd_create failed: ") + err);
+    return ctx;
 }
 
 HipSEPAIHRDObjectiveFunction::~HipSEPAIHRDObjectiveFunction() { sepaihrd_destroy(ctx_); }
@@ -390,6 +408,98 @@ double HipSEPAIHRDObjectiveFunction::calculate(const Eigen::VectorXd& parameters
     if (fast) fast->storeLikelihood(fast_key, value);
     else cache_.storeLikelihood(key, value);
     return value;
+}
+
+// ------------------------------------------------------------------ finite-difference gradient objective
+HipSEPAIHRDGradientObjectiveFunction::HipSEPAIHRDGradientObjectiveFunction(
+    HipSEPAIHRDParameterManager& parameterManager, ISimulationCache& cache, const CalibrationData& data,
+    const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+    std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error, double rel_error, int device,
+    bool fma_arithmetic)
+    : HipSEPAIHRDObjectiveFunction(parameterManager, cache, data, time_points, initial_state, solver_strategy, abs_error,
+                                   rel_error, device, fma_arithmetic),
+      initial_state_(initial_state), n_times_(time_points.size()),
+      n_obs_rows_(static_cast<size_t>(data.getNewDeaths().rows())), first_time_(time_points.empty() ? 0.0 : time_points.front()) {
+    // perturbed runs: multipliers default to 1.0 unless calibrated (:59-72), always the multiplier rule
+    const double ones[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    const ConstraintMode keep = pm_.getConstraintMode();
+    pm_.setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);  // the temporary manager's default mode (:40-43)
+    try {
+        grad_ctx_ = createContext(pm_, data, time_points, initial_state, solver_strategy, abs_error, rel_error, device,
+                                  fma_arithmetic, ones);
+    } catch (...) {
+        pm_.setConstraintMode(keep);
+        throw;
+    }
+    pm_.setConstraintMode(keep);
+    sepaihrd_set_initial_state_mode(grad_ctx_, SEPAIHRD_INIT_MULTIPLIERS);
+    const std::vector<int32_t>& codes = pm_.fieldCodes();
+    mult_index_.assign(8, -1);
+    for (size_t k = 0; k < codes.size(); ++k)
+        if (codes[k] >= SEPAIHRD_F_E0_MULT && codes[k] <= SEPAIHRD_F_D0_MULT && mult_index_[static_cast<size_t>(codes[k] - SEPAIHRD_F_E0_MULT)] < 0)
+            mult_index_[static_cast<size_t>(codes[k] - SEPAIHRD_F_E0_MULT)] = static_cast<int>(k);
+}
+
+HipSEPAIHRDGradientObjectiveFunction::~HipSEPAIHRDGradientObjectiveFunction() { sepaihrd_destroy(grad_ctx_); }
+
+bool HipSEPAIHRDGradientObjectiveFunction::initialStateValid(const double* plus) const {
+    const Eigen::VectorXd& N = pm_.modelParameters().N;
+    const int n = static_cast<int>(N.size());
+    for (int k = 0; k < n; ++k) {
+        double sum = 0.0;
+        for (int j = 1; j <= 8; ++j) {  // E .. D: the population compartments besides S (:88-92)
+            const int idx = mult_index_[static_cast<size_t>(j - 1)];
+            const double mult = idx >= 0 ? plus[idx] : 1.0;
+            sum += initial_state_[j * n + k] * mult;
+        }
+        if (sum > N[k] || sum < 0) return false;
+    }
+    return true;
+}
+
+double HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient(const Eigen::VectorXd& params, Eigen::VectorXd& grad) const {
+    const double LOWEST = std::numeric_limits<double>::lowest();
+    const int P = static_cast<int>(params.size());
+    grad.resize(P);
+    const double f_center = HipSEPAIHRDObjectiveFunction::calculate(params);  // :22
+    if (!std::isfinite(f_center)) {  // :24-29
+        for (int i = 0; i < P; ++i) grad[i] = 0.0;
+        return f_center;
+    }
+    std::vector<double> plus(static_cast<size_t>(P) * P), eps(static_cast<size_t>(P));
+    for (int i = 0; i < P; ++i) {
+        const double param_scale = std::max(std::abs(params[i]), epsilon_);
+        eps[static_cast<size_t>(i)] = epsilon_ * param_scale;
+        for (int k = 0; k < P; ++k) plus[static_cast<size_t>(i) * P + k] = params[k];
+        plus[static_cast<size_t>(i) * P + i] += eps[static_cast<size_t>(i)];
+    }
+    std::vector<double> f_plus(static_cast<size_t>(P), LOWEST);
+    std::vector<int32_t> status(static_cast<size_t>(P), 0);
+    const bool rows_match = n_times_ == n_obs_rows_;
+    if (rows_match) {
+        if (first_time_ < 0.0)
+            throw InvalidParameterException("SEPAIHRDGradientObjectiveFunction",
+                                            "output grids that start before t = 0 with one observation row per output are not built");
+        const int rc = sepaihrd_eval_batch(grad_ctx_, plus.data(), P, f_plus.data(), status.data(), nullptr, nullptr, nullptr, nullptr);
+        if (rc != SEPAIHRD_OK) throw ModelException("SEPAIHRDGradientObjectiveFunction", sepaihrd_last_error(grad_ctx_));
+    }
+    for (int i = 0; i < P; ++i) {
+        const size_t u = static_cast<size_t>(i);
+        const bool valid = initialStateValid(&plus[u * P]);
+        if (!valid) { grad[i] = 0.0; continue; }  // :94-104
+        double fp;
+        if (!rows_match) {
+            // every stream fails calculateSingleLogLikelihood's dimension check: lowest() three times,
+            // -inf, then mapped to lowest() (:148-155); the simulation result is not used
+            fp = LOWEST;
+        } else {
+            if (status[u] >= SEPAIHRD_STATUS_STEP_FAILURE)
+                throw SimulationException("Dopri5SolverStrategy::integrate", "Boost.Odeint integration failed: step size adjustment");
+            fp = f_plus[u];  // status 1 with a valid state: non-finite likelihood, already lowest()
+        }
+        grad[i] = std::isfinite(fp) ? (fp - f_center) / eps[u] : 0.0;  // :163-167
+    }
+    return f_center;
 }
 
 }  // namespace epidemic

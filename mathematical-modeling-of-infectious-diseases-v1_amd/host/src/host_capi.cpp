@@ -338,4 +338,31 @@ int host_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int t
     }
 }
 
+// HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient over the handle's parameter manager / data.
+// returns 0 ok, 1 = exception (message in host_last_error)
+int host_gradient(void* hv, const sepaihrd_problem* pb, int device, const double* theta, double epsilon, double* value,
+                  double* grad) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int n = pb->n_age;
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        std::shared_ptr<IOdeSolverStrategy> solver;
+        if (pb->solver == SEPAIHRD_SOLVER_CASH_KARP54) solver = std::make_shared<CashKarpSolverStrategy>();
+        else solver = std::make_shared<Dopri5SolverStrategy>();
+        SimulationCache cache(16);
+        HipSEPAIHRDGradientObjectiveFunction obj(*h->pm, cache, *h->data, std::vector<double>(pb->times, pb->times + pb->n_times),
+                                                 vec(pb->initial_state, 11 * n), solver, pb->abs_err, pb->rel_err, device,
+                                                 pb->arith == SEPAIHRD_ARITH_FMA);
+        obj.epsilon_ = epsilon;
+        Eigen::VectorXd g;
+        IGradientObjectiveFunction& iface = obj;  // through the interface NUTS uses (NUTSSampler.cpp:80)
+        *value = iface.evaluate_with_gradient(vec(theta, P), g);
+        for (int i = 0; i < P; ++i) grad[i] = g[i];
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
 }  // extern "C"

@@ -39,6 +39,7 @@ def load_library() -> C.CDLL:
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_gradient.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_double, vp, vp]
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -88,6 +89,18 @@ class HostObjective:
             raise RuntimeError("host_hc_run: " + self.lib.host_last_error().decode())
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace,
                 "evaluations": ne.value, "launches": nl.value}
+
+    def evaluate_with_gradient(self, theta, epsilon: float = 1e-4, device: int = -1):
+        """HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient: (value, gradient)."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        keep: list = []
+        st = hipabi.build_problem_struct(self.pb, keep)
+        g = np.empty(self.P)
+        v = C.c_double(0.0)
+        rc = self.lib.host_gradient(self.h, C.byref(st), device, th.ctypes.data, epsilon, C.byref(v), g.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("host_gradient: " + self.lib.host_last_error().decode())
+        return v.value, g
 
     def calibrate(self, hc_seed: int, mh_seed: int, hc_iterations: int, mh_iterations: int, burn_in: int,
                   cloud_size_multiplier: int = 8, threads: int = 16, adaptation_period: int = 100, thinning: int = 1,

@@ -249,6 +249,17 @@ int oracle_hc(void* hv, int iterations, int cloud_size_multiplier, int threads, 
     return 0;
 }
 
+int oracle_gradient(void* hv, const double* theta, double epsilon, double* value, double* grad) {
+    auto* h = static_cast<Handle*>(hv);
+    const int P = static_cast<int>(h->pb.pm.names.size());
+    std::vector<double> g;
+    try {
+        *value = oracle::evaluate_with_gradient(h->pb, std::vector<double>(theta, theta + P), g, epsilon);
+    } catch (const std::exception&) { return 2; }
+    std::copy(g.begin(), g.end(), grad);
+    return 0;
+}
+
 int oracle_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
                      int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed,
                      const double* x0, double* best, double* best_value, double* initial_value,

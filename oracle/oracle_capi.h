@@ -57,6 +57,8 @@ int oracle_ensemble(void *h, const double *theta, int S, const double *probs, in
 /* HillClimbingOptimizer restated (seeded, virtual threads).  trace: [iterations] current logL. */
 int oracle_hc(void *h, int iterations, int cloud_size_multiplier, int threads, const double *x0, uint32_t seed,
               double *best, double *best_value, double *final_cov, double *trace, long *evaluations);
+/* SEPAIHRDGradientObjectiveFunction::evaluate_with_gradient restated; returns 0, or 2 when an integration throws */
+int oracle_gradient(void *h, const double *theta, double epsilon, double *value, double *grad);
 /* ModelCalibrator restated: HC phase (clamp) -> covariance conditioning -> one MH chain (reflect).
  * samples capacity: (mh_iterations / thinning + 1) x P.  All outputs nullable except best/best_value. */
 int oracle_calibrate(void *h, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,

@@ -70,6 +70,7 @@ def load(path: str | None = None) -> C.CDLL:
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.oracle_gradient.argtypes = [vp, vp, C.c_double, vp, vp]
     lib.oracle_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_condition_covariance.argtypes = [vp, vp, vp]
@@ -182,6 +183,15 @@ class Oracle:
         self.lib.oracle_hc(self.h, iterations, cloud_size_multiplier, threads, x0.ctypes.data, seed, best.ctypes.data,
                            C.byref(bv), cov.ctypes.data, trace.ctypes.data, C.byref(ne))
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace, "evaluations": ne.value}
+
+    def evaluate_with_gradient(self, theta, epsilon: float = 1e-4):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        g = np.empty(self.P)
+        v = C.c_double(0.0)
+        rc = self.lib.oracle_gradient(self.h, th.ctypes.data, epsilon, C.byref(v), g.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("SimulationException")
+        return v.value, g
 
     def condition_covariance(self, cov) -> np.ndarray:
         c = np.ascontiguousarray(cov, dtype=np.float64)

@@ -752,6 +752,83 @@ inline double objective(const Problem& pb, const std::vector<double>& theta, Eva
 }
 
 // -----------------------------------------------------------------------------
+// SEPAIHRDGradientObjectiveFunction::evaluate_with_gradient
+// (src/model/objectives/SEPAIHRDGradientObjectiveFunction.cpp:15-171): forward differences,
+// eps_i = epsilon max(|theta_i|, epsilon).  The perturbed runs do NOT go through calculate():
+//   * a fresh parameter manager (default OPTIMIZATION_CLAMP mode) updates a cloned model (:40-54);
+//   * the initial state is ALWAYS problem.initial_state scaled by the multipliers, which are read
+//     from the UNCONSTRAINED perturbed vector by name and default to 1.0 when not calibrated (:59-83);
+//   * S by subtraction, invalid (gradient entry 0) when the non-S total exceeds N or is negative (:85-101);
+//   * the three Poisson terms use ALL output rows, so a row count different from the observations'
+//     makes each of them lowest() (calculateSingleLogLikelihood's dimension check) (:126-158);
+//   * a non-finite sum becomes lowest(), which is finite, so the difference quotient is still formed.
+// -----------------------------------------------------------------------------
+inline double evaluate_with_gradient(const Problem& pb, const std::vector<double>& theta, std::vector<double>& grad,
+                                     double epsilon = 1e-4) {
+    const double LOWEST = std::numeric_limits<double>::lowest();
+    const int P = static_cast<int>(theta.size());
+    grad.assign(P, 0.0);
+    EvalInfo info;
+    const double f_center = objective(pb, theta, &info);
+    if (info.status >= 2) throw std::runtime_error("SimulationException");
+    if (!std::isfinite(f_center)) return f_center;
+    const int n = pb.base.n;
+    const size_t T = pb.time_points.size();
+    static const char* mult_names[8] = {"E0_multiplier", "P0_multiplier", "A0_multiplier", "I0_multiplier",
+                                        "H0_multiplier", "ICU0_multiplier", "R0_multiplier", "D0_multiplier"};
+    for (int i = 0; i < P; ++i) {
+        const double param_scale = std::max(std::abs(theta[i]), epsilon);
+        const double eps_i = epsilon * param_scale;
+        Model model(pb.base);
+        ParameterManager temp = pb.pm;
+        temp.mode = OPTIMIZATION_CLAMP;
+        std::vector<double> plus = theta;
+        plus[i] += eps_i;
+        try {
+            temp.updateModelParameters(plus, model);
+        } catch (...) { grad[i] = 0.0; continue; }
+        state_type init = pb.initial_state;
+        for (int c = 1; c <= 8; ++c) {
+            double mult = 1.0;
+            for (int k = 0; k < P; ++k)
+                if (pb.pm.names[k] == mult_names[c - 1]) { mult = plus[k]; break; }
+            for (int a = 0; a < n; ++a) init[c * n + a] *= mult;
+        }
+        bool valid = true;
+        for (int a = 0; a < n; ++a) {
+            double sum = 0.0;
+            for (int j = 1; j < NUM_POPULATION_COMPARTMENTS; ++j) sum += init[j * n + a];
+            if (sum > model.P.N[a] || sum < 0) { valid = false; break; }
+            init[a] = model.P.N[a] - sum;
+        }
+        if (!valid) { grad[i] = 0.0; continue; }
+        thread_local SimulationResult res;
+        StepStats st;
+        st.max_attempts = pb.max_attempts;
+        simulate(res, model, init, pb.time_points, pb.solver, pb.dt_hint, pb.abs_err, pb.rel_err, &st);
+        double f_plus;
+        if (static_cast<int>(T) != pb.num_obs_rows) {
+            f_plus = LOWEST + LOWEST + LOWEST;  // -inf
+        } else {
+            std::vector<double> sh(T * n), si(T * n), sd(T * n);
+            auto diff = [&](std::vector<double>& out, int comp) {
+                for (int a = 0; a < n; ++a) out[a] = res.row(0)[comp * n + a] - init[comp * n + a];
+                for (size_t k = 1; k < T; ++k)
+                    for (int a = 0; a < n; ++a) out[k * n + a] = res.row(k)[comp * n + a] - res.row(k - 1)[comp * n + a];
+                for (double& v : out) v = std::max(v, 0.0);
+            };
+            diff(sh, 9); diff(si, 10); diff(sd, 8);
+            const int rows = static_cast<int>(T);
+            f_plus = poisson_loglik(sh.data(), pb.obs_H.data(), rows, n) + poisson_loglik(si.data(), pb.obs_ICU.data(), rows, n) +
+                     poisson_loglik(sd.data(), pb.obs_D.data(), rows, n);
+        }
+        if (std::isnan(f_plus) || std::isinf(f_plus)) f_plus = LOWEST;
+        grad[i] = std::isfinite(f_plus) ? (f_plus - f_center) / eps_i : 0.0;
+    }
+    return f_center;
+}
+
+// -----------------------------------------------------------------------------
 // Posterior ensemble (second consumer of the integrator).
 //   SimulationRunner::runSimulation       src/model/SimulationRunner.cpp:24-104
 //     theta -> model (updateModelParameters, PostCalibrationAnalyser.cpp:212-218), then the

@@ -133,3 +133,45 @@ def test_two_phase_calibration_follows_the_reference_flow(mm, oracle_py, shipped
     # the other chains start from the same optimum with their own streams
     assert not np.array_equal(got["accept_trace"][1], got["accept_trace"][0])
     assert got["best_value"] >= ref["best_value"] * (1 - 1e-10)
+
+
+def _multiplier_fixture(mm, ref_fixture):
+    """reference test fixture + calibrated E0 / I0 multipliers (the finite-difference objective reads them)."""
+    pb = ref_fixture
+    names = list(pb.param_names) + ["E0_multiplier", "I0_multiplier"]
+    sig = dict(pb.sigmas); sig.update(E0_multiplier=0.05, I0_multiplier=0.05)
+    bnd = dict(pb.bounds); bnd.update(E0_multiplier=(0.5, 1.2), I0_multiplier=(0.1, 3.0))
+    theta = np.concatenate([np.asarray(pb.base_theta), [1.2, 0.8]])  # E0 multiplier AT its upper bound
+    return pb.with_(param_names=names, sigmas=sig, bounds=bnd, base_theta=theta, arith=mm.ARITH_STRICT, constraint_mode=0)
+
+
+def test_finite_difference_gradient_objective(mm, oracle_py, ref_fixture):
+    """HipSEPAIHRDGradientObjectiveFunction (P perturbed runs in one launch) == the restatement of
+    SEPAIHRDGradientObjectiveFunction.cpp:15-171, incl. a multiplier perturbed past its upper bound
+    (the reference reads it unconstrained)."""
+    pb = _multiplier_fixture(mm, ref_fixture)
+    theta = np.asarray(pb.base_theta)
+    ref_v, ref_g = oracle_py.Oracle(pb).evaluate_with_gradient(theta)
+    got_v, got_g = mm.HostObjective(pb).evaluate_with_gradient(theta)
+    np.testing.assert_allclose(got_v, ref_v, rtol=1e-11)
+    assert np.all(np.isfinite(ref_g)) and np.count_nonzero(ref_g) >= 4
+    # the difference quotient divides the 1e-12-relative log / pow differences by eps ~ 1e-4 |theta|
+    scale = np.abs(ref_v) * 1e-10 / (1e-4 * np.maximum(np.abs(theta), 1e-4))
+    assert np.all(np.abs(got_g - ref_g) <= np.maximum(1e-6 * np.abs(ref_g), scale)), (got_g, ref_g)
+    # differentiating the smooth parameters by hand agrees with the quotient's sign and size
+    k = pb.param_names.index("beta")
+    h = 1e-4 * max(abs(theta[k]), 1e-4)
+    tp = theta.copy(); tp[k] += h
+    o = oracle_py.Oracle(pb)
+    assert np.isclose((o.calculate(tp) - o.calculate(theta)) / h, ref_g[k], rtol=1e-6)
+
+
+def test_finite_difference_gradient_row_mismatch_follows_the_reference(mm, oracle_py, shipped):
+    """With run-up output rows the reference's perturbed likelihood fails its dimension check:
+    every entry is (lowest() - f) / eps (here -inf), no simulation is needed for it."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT)
+    theta = np.asarray(pb.base_theta)
+    ref_v, ref_g = oracle_py.Oracle(pb).evaluate_with_gradient(theta)
+    got_v, got_g = mm.HostObjective(pb).evaluate_with_gradient(theta)
+    np.testing.assert_allclose(got_v, ref_v, rtol=1e-11)
+    assert np.array_equal(got_g, ref_g) and np.all(np.isneginf(ref_g))
