@@ -18,7 +18,10 @@
 //     (tests/model/SEPAIHRDObjectivefunctionTest.cpp:688-752, tol 1e-8);
 //   * structural properties of calculate() (same file :334-685).
 // Independent cross-checks (SciPy DOP853 / Radau at rtol 1e-12, mpmath RHS
-// values) are committed under tests/golden/ with their generating script.
+// values) are committed under tests/golden/ with their generating script, and
+// tests/test_oracle_independent_steps.py pins one step of each stepper, the error
+// norm / accept rule and both step-size rules against SciPy's RK45 tableau and
+// the published Cash-Karp tableau (no code shared with this file).
 //
 // Every function cites the reference file:line it follows (paths relative to
 // /root/reference).
