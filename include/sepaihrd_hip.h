@@ -229,6 +229,46 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, c
                                 int n_probs, double *ppc_quantiles, double *sero_quantiles,
                                 int32_t *status, int32_t *n_valid);
 
+/* ---- Adaptive-Metropolis chains with their state resident on the device ----
+ *
+ * MetropolisHastingsSampler (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:201-412)
+ * keeps per chain: current state, proposal covariance and its Cholesky factor, running mean and the
+ * whole chain history, from which the covariance is recomputed every adaptation period (:168-199,
+ * O(t P^2)).  For C lock-step chains that state (C t P doubles of history) and that work live next to the
+ * likelihood kernel.  The caller keeps what must stay serial per chain: the std::mt19937 stream (its
+ * draw order depends on the accept test), the accept decision and the scalar scale adaptation.
+ * Every sum runs in the reference's order without contraction: a host loop doing the same arithmetic
+ * gets the same bits.
+ *
+ *   create    x0 [C][P] host; cov0 [P][P] row-major host = the initial covariance of EVERY chain,
+ *             regularisation already added (:219-237); its Cholesky factor is taken on the device,
+ *             0.1 I when it is not positive definite (:240-246); history row 0 = x0, mean = x0.
+ *             capacity = history rows per chain (the number of iterations incl. iteration 0).
+ *   evaluate_current  log-likelihood of the current states (:257)
+ *   propose   prop = applyConstraints(x + scale_c L_c z_c) for every chain, evaluated: z [C][P], scale [C],
+ *             loglik [C], status [C] (nullable) host (:91-102,309-312).  loglik == NULL only launches: the
+ *             caller overlaps its own work with the evaluation and collects the values with fetch
+ *   commit    accept [C] (0/1) host: x <- prop where set, the state is appended to the history (:332-371)
+ *   adapt     rank-one update with gamma from the newest history row (:154-166); if refresh != 0 the
+ *             adaptation-period step (:283-301): full two-pass recompute when recompute_full != 0
+ *             (caller checks history >= P + 10), then the Cholesky factor of cov + eps I, kept on success
+ *   read_history / read_covariance   rows of the history [C][n_rows][P], covariances [C][P][P]
+ * P <= 128. */
+typedef struct sepaihrd_mh sepaihrd_mh;
+sepaihrd_mh *sepaihrd_mh_create(sepaihrd_ctx *ctx, int C, int capacity, const double *x0, const double *cov0,
+                                double reg_eps, double scaling_factor);
+void sepaihrd_mh_destroy(sepaihrd_mh *mh);
+int sepaihrd_mh_evaluate_current(sepaihrd_mh *mh, double *loglik, int32_t *status);
+int sepaihrd_mh_propose(sepaihrd_mh *mh, const double *z, const double *scale, double *loglik, int32_t *status);
+int sepaihrd_mh_fetch(sepaihrd_mh *mh, double *loglik, int32_t *status);
+int sepaihrd_mh_commit(sepaihrd_mh *mh, const uint8_t *accept);
+int sepaihrd_mh_adapt(sepaihrd_mh *mh, double gamma, int refresh, int recompute_full);
+int sepaihrd_mh_read_history(sepaihrd_mh *mh, const int32_t *rows, int n_rows, double *out);
+int sepaihrd_mh_read_covariance(sepaihrd_mh *mh, double *cov);
+/* the constrained proposals of the last propose call, [C][P] (callers that track the best state) */
+int sepaihrd_mh_read_proposal(sepaihrd_mh *mh, double *prop);
+int sepaihrd_mh_history_length(const sepaihrd_mh *mh);
+
 /* applyConstraints for B vectors on the host (exactly the device's arithmetic). */
 int sepaihrd_apply_constraints(const sepaihrd_ctx *ctx, int mode, const double *in, int B, double *out);
 

@@ -665,4 +665,204 @@ int sepaihrd_get_kernel_info(sepaihrd_ctx* ctx, sepaihrd_kernel_info* info) {
     return SEPAIHRD_OK;
 }
 
+// ------------------------------------------------------------------ device-resident Adaptive Metropolis
+struct sepaihrd_mh {
+    sepaihrd_ctx* ctx = nullptr;
+    SamplerState st{};
+    int rows = 0;  // history rows written so far
+    double* d_z = nullptr;
+    double* d_scale = nullptr;
+    double* d_loglik = nullptr;
+    int32_t* d_status = nullptr;
+    uint8_t* d_accept = nullptr;
+    int32_t* d_rows = nullptr;
+    double* d_gather = nullptr;
+    size_t gather_cap = 0;
+    std::vector<void*> allocs;
+};
+
+namespace {
+int mh_eval(sepaihrd_mh* mh, const double* d_theta, double* loglik, int32_t* status) {
+    sepaihrd_ctx* ctx = mh->ctx;
+    const int C = mh->st.C;
+    const int rc = sepaihrd_eval_batch_device(ctx, d_theta, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc != SEPAIHRD_OK) return rc;
+    HIP_TRY(hipMemcpy(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (status)
+        HIP_TRY(hipMemcpy(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+}  // namespace
+
+sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const double* x0, const double* cov0,
+                                double reg_eps, double scaling_factor) {
+    if (!ctx) return nullptr;
+    const int P = ctx->P;
+    if (C <= 0 || capacity <= 0 || !x0 || !cov0 || P > 128) {
+        ctx->last_error = "mh_create: need C > 0, capacity > 0, x0, cov0 and at most 128 parameters";
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->last_error = "hipSetDevice failed"; return nullptr; }
+    auto* mh = new sepaihrd_mh();
+    mh->ctx = ctx;
+    SamplerState& st = mh->st;
+    st.C = C; st.P = P; st.capacity = capacity; st.scaling = scaling_factor; st.reg_eps = reg_eps;
+    const size_t CP = (size_t)C * P, CPP = CP * P;
+    bool ok = true;
+    auto dalloc = [&](void** p, size_t bytes) {
+        if (!ok) return;
+        if (hipMalloc(p, bytes) != hipSuccess) { ok = false; return; }
+        mh->allocs.push_back(*p);
+    };
+    dalloc((void**)&st.x, CP * sizeof(double));
+    dalloc((void**)&st.prop, CP * sizeof(double));
+    dalloc((void**)&st.cov, CPP * sizeof(double));
+    dalloc((void**)&st.chol, CPP * sizeof(double));
+    dalloc((void**)&st.mean, CP * sizeof(double));
+    dalloc((void**)&st.hist, CP * (size_t)capacity * sizeof(double));
+    dalloc((void**)&mh->d_z, CP * sizeof(double));
+    dalloc((void**)&mh->d_scale, (size_t)C * sizeof(double));
+    dalloc((void**)&mh->d_loglik, (size_t)C * sizeof(double));
+    dalloc((void**)&mh->d_status, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&mh->d_accept, (size_t)C);
+    if (ok && sepaihrd_reserve(ctx, C) != SEPAIHRD_OK) ok = false;
+    if (ok) {
+        std::vector<double> cov_all(CPP);
+        for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
+        ok = hipMemcpy(st.x, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(st.mean, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(st.cov, cov_all.data(), CPP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemset(st.chol, 0, CPP * sizeof(double)) == hipSuccess;
+    }
+    if (ok) ok = sampler_cholesky(st, 0.0, 1, nullptr) == 0 && sampler_commit(st, nullptr, 0, nullptr) == 0 &&
+                 hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        ctx->last_error = "mh_create: device allocation or initialisation failed (history = C * capacity * P doubles)";
+        for (void* p : mh->allocs) (void)hipFree(p);
+        delete mh;
+        return nullptr;
+    }
+    mh->rows = 1;
+    return mh;
+}
+
+void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
+    if (!mh) return;
+    (void)hipSetDevice(mh->ctx->device);
+    for (void* p : mh->allocs) (void)hipFree(p);
+    if (mh->d_rows) (void)hipFree(mh->d_rows);
+    if (mh->d_gather) (void)hipFree(mh->d_gather);
+    delete mh;
+}
+
+int sepaihrd_mh_history_length(const sepaihrd_mh* mh) { return mh ? mh->rows : 0; }
+
+int sepaihrd_mh_evaluate_current(sepaihrd_mh* mh, double* loglik, int32_t* status) {
+    if (!mh || !loglik) return SEPAIHRD_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(mh->ctx->device), mh->ctx, return SEPAIHRD_E_HIP);
+    return mh_eval(mh, mh->st.x, loglik, status);
+}
+
+int sepaihrd_mh_propose(sepaihrd_mh* mh, const double* z, const double* scale, double* loglik, int32_t* status) {
+    if (!mh || !z || !scale) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const size_t CP = (size_t)mh->st.C * mh->st.P;
+    HIP_TRY(hipMemcpy(mh->d_z, z, CP * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(mh->d_scale, scale, (size_t)mh->st.C * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    if (sampler_propose(mh->st, ctx->dp, mh->d_z, mh->d_scale, nullptr) != 0) {
+        ctx->last_error = "mh_propose: launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    if (!loglik)  // launch only: the caller overlaps host work and calls sepaihrd_mh_fetch
+        return sepaihrd_eval_batch_device(ctx, mh->st.prop, mh->st.C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr);
+    return mh_eval(mh, mh->st.prop, loglik, status);
+}
+
+int sepaihrd_mh_fetch(sepaihrd_mh* mh, double* loglik, int32_t* status) {
+    if (!mh || !loglik) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const int C = mh->st.C;
+    HIP_TRY(hipMemcpy(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (status)
+        HIP_TRY(hipMemcpy(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_commit(sepaihrd_mh* mh, const uint8_t* accept) {
+    if (!mh || !accept) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (mh->rows >= mh->st.capacity) {
+        ctx->last_error = "mh_commit: history capacity exhausted";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(mh->d_accept, accept, (size_t)mh->st.C, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    if (sampler_commit(mh->st, mh->d_accept, mh->rows, nullptr) != 0) {
+        ctx->last_error = "mh_commit: launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    mh->rows++;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_adapt(sepaihrd_mh* mh, double gamma, int refresh, int recompute_full) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    int rc = sampler_rank1(mh->st, gamma, mh->rows - 1, nullptr);
+    if (rc == 0 && refresh) {
+        if (recompute_full) {
+            rc = sampler_full_covariance(mh->st, mh->rows, nullptr);
+            if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, nullptr);  // :190-197, kept on success
+        }
+        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, nullptr);  // :295-300
+    }
+    if (rc != 0) {
+        ctx->last_error = "mh_adapt: launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_history(sepaihrd_mh* mh, const int32_t* rows, int n_rows, double* out) {
+    if (!mh || !rows || n_rows <= 0 || !out) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const int C = mh->st.C, P = mh->st.P;
+    for (int r = 0; r < n_rows; ++r)
+        if (rows[r] < 0 || rows[r] >= mh->rows) {
+            ctx->last_error = "mh_read_history: row out of range";
+            return SEPAIHRD_E_INVALID_ARG;
+        }
+    HIP_TRY(hipDeviceSynchronize(), ctx, return SEPAIHRD_E_HIP);
+    // strided copies straight out of the history: row r of every chain = a 2-D region
+    for (int r = 0; r < n_rows; ++r)
+        HIP_TRY(hipMemcpy2D(out + (size_t)r * P, (size_t)n_rows * P * sizeof(double),
+                            mh->st.hist + (size_t)rows[r] * P, (size_t)mh->st.capacity * P * sizeof(double),
+                            (size_t)P * sizeof(double), (size_t)C, hipMemcpyDeviceToHost),
+                ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_proposal(sepaihrd_mh* mh, double* prop) {
+    if (!mh || !prop) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(prop, mh->st.prop, (size_t)mh->st.C * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
+            return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_covariance(sepaihrd_mh* mh, double* cov) {
+    if (!mh || !cov) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(cov, mh->st.cov, (size_t)mh->st.C * mh->st.P * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
+            return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
 }  // extern "C"

@@ -132,4 +132,21 @@ inline size_t eval_lds_bytes(const DevProblem& pb) {
            sizeof(double);
 }
 
+// ---- Adaptive-Metropolis state of C chains resident in HBM (csrc/sepaihrd_sampler.hip) ----
+struct SamplerState {
+    int32_t C, P, capacity;   // chains, parameters, history rows allocated per chain
+    double scaling, reg_eps;  // 2.38^2 / P and the regularisation epsilon of the covariance refresh
+    double* x;      // [C][P] current state
+    double* prop;   // [C][P] last proposal (after applyConstraints)
+    double* cov;    // [C][P][P] proposal covariance, row-major
+    double* chol;   // [C][P][P] its lower Cholesky factor
+    double* mean;   // [C][P] running mean
+    double* hist;   // [C][capacity][P] every state of every chain
+};
+int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
+int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
+int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream);
+int sampler_full_covariance(const SamplerState& s, int len, void* stream);
+int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream);
+
 }  // namespace sepaihrd

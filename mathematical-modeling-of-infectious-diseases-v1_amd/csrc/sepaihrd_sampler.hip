@@ -1,0 +1,216 @@
+// =============================================================================
+// csrc/sepaihrd_sampler.hip -- per-chain Adaptive-Metropolis state resident in HBM.
+//
+// The reference's MetropolisHastingsSampler keeps, per chain, the current state, the proposal
+// covariance, its Cholesky factor, the running mean and the whole chain history, and every
+// `adaptation_period` iterations recomputes the covariance from that history in two passes
+// (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:154-199,295-300).  For one chain
+// that is nothing; for thousands of chains in lock-step it is O(C t P^2) work per refresh and C t P
+// doubles of history, which belongs next to the likelihood kernel, not on the host.
+//
+// What stays on the host: the random streams (std::mt19937 + libstdc++ distributions, whose draw
+// order depends on the accept test), the accept decision and the scalar scale adaptation.
+// What lives here (one launch each, all chains):
+//   propose   prop = applyConstraints(x + scale * L z)                      (:91-102,309)
+//   commit    x <- prop where accepted, history append                      (:332-340,371)
+//   rank-one  cov <- (1-g) cov + g d d^T, mean <- mean + g d, d = x_new - mean   (:154-166)
+//   full      two-pass sample covariance over the history, scaled + epsilon (:168-199)
+//   cholesky  lower factor, kept only when the matrix is positive definite  (:240-246,295-300)
+// Every sum runs in the reference's order (history rows ascending, k ascending in the Cholesky
+// recurrences) and this file is compiled with -ffp-contract=off, so the numbers are those of the
+// host loop bit for bit (tests compare accept traces, samples and covariances with it).
+// =============================================================================
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sepaihrd_device.h"
+
+namespace sepaihrd {
+namespace {
+
+// SEPAIHRDParameterManager.cpp:302-313 / :326-343 (same code as the evaluation kernel's)
+__device__ __forceinline__ double reflect_bound(double value, double minb, double maxb) {
+    if (minb >= maxb) return minb;
+    const double width = maxb - minb;
+    double y = fmod(value - minb, 2.0 * width);
+    if (y < 0) y += 2.0 * width;
+    if (y <= width) return minb + y;
+    return maxb - (y - width);
+}
+__device__ __forceinline__ double constrain(double v, double lo, double hi, int has_bounds, int mode) {
+    if (has_bounds) {
+        if (lo > hi) { const double t = lo; lo = hi; hi = t; }
+        if (mode == 0) {
+            const double m = (v < lo) ? lo : v;
+            return (hi < m) ? hi : m;
+        }
+        return reflect_bound(v, lo, hi);
+    }
+    if (mode == 0) return (0.0 < v) ? v : 0.0;
+    return fabs(v);
+}
+
+// prop_i = constrain(x_i + scale * sum_{j <= i} L_ij z_j), j ascending
+__global__ void mh_propose_kernel(const SamplerState s, const DevProblem pb, const double* z, const double* scale) {
+    const int c = blockIdx.x;
+    const int P = s.P;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double* Lrow = s.chol + ((size_t)c * P + i) * P;
+        const double* zc = z + (size_t)c * P;
+        double sum = 0.0;
+        for (int j = 0; j <= i; ++j) sum += Lrow[j] * zc[j];
+        const double raw = s.x[(size_t)c * P + i] + scale[c] * sum;
+        s.prop[(size_t)c * P + i] = constrain(raw, pb.lower[i], pb.upper[i], pb.has_bounds[i], pb.constraint_mode);
+    }
+}
+
+__global__ void mh_commit_kernel(const SamplerState s, const uint8_t* accept, const int row) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)s.C * s.P) return;
+    const int c = (int)(idx / s.P), i = (int)(idx % s.P);
+    double v = s.x[idx];
+    if (accept != nullptr && accept[c]) { v = s.prop[idx]; s.x[idx] = v; }
+    s.hist[((size_t)c * s.capacity + row) * s.P + i] = v;
+}
+
+// rank-one update, covariance part; d uses the mean BEFORE this iteration's update
+__global__ void mh_rank1_cov_kernel(const SamplerState s, const double gamma, const int last_row) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t PP = (size_t)s.P * s.P;
+    if (idx >= (size_t)s.C * PP) return;
+    const int c = (int)(idx / PP);
+    const int i = (int)((idx % PP) / s.P), j = (int)(idx % s.P);
+    const double* ns = s.hist + ((size_t)c * s.capacity + last_row) * s.P;
+    const double* m = s.mean + (size_t)c * s.P;
+    const double di = ns[i] - m[i], dj = ns[j] - m[j];
+    s.cov[idx] = (1.0 - gamma) * s.cov[idx] + gamma * (di * dj);
+}
+__global__ void mh_rank1_mean_kernel(const SamplerState s, const double gamma, const int last_row) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)s.C * s.P) return;
+    const int c = (int)(idx / s.P), i = (int)(idx % s.P);
+    const double d = s.hist[((size_t)c * s.capacity + last_row) * s.P + i] - s.mean[idx];
+    s.mean[idx] += gamma * d;
+}
+
+// pass 1 of recomputeFullCovariance: mean_i = (sum_s h[s][i]) / len, s ascending
+__global__ void mh_full_mean_kernel(const SamplerState s, const int len) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)s.C * s.P) return;
+    const int c = (int)(idx / s.P), i = (int)(idx % s.P);
+    const double* h = s.hist + (size_t)c * s.capacity * s.P + i;
+    double m = 0.0;
+    for (int r = 0; r < len; ++r) m += h[(size_t)r * s.P];
+    s.mean[idx] = m / (double)len;
+}
+
+// pass 2: acc_ij = sum_s (h[s][i] - mean_i) (h[s][j] - mean_j), s ascending;
+// cov_ij = scaling (acc_ij / (len - 1)) + (i == j ? eps : 0).  A thread owns one j and IT rows i:
+// each history row is read once per IT rows instead of once per row.
+constexpr int IT = 8;
+__global__ __launch_bounds__(WAVE) void mh_full_cov_kernel(const SamplerState s, const int len) {
+    const int c = blockIdx.x;
+    const int i0 = blockIdx.y * IT;
+    const int j = blockIdx.z * WAVE + threadIdx.x;
+    const int P = s.P;
+    const bool live = j < P;
+    const double* h = s.hist + (size_t)c * s.capacity * P;
+    const double* m = s.mean + (size_t)c * P;
+    const double mj = live ? m[j] : 0.0;
+    double mi[IT], acc[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { mi[k] = (i0 + k < P) ? m[i0 + k] : 0.0; acc[k] = 0.0; }
+    for (int r = 0; r < len; ++r) {
+        const double* row = h + (size_t)r * P;
+        const double dj = (live ? row[j] : 0.0) - mj;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const double di = ((i0 + k < P) ? row[i0 + k] : 0.0) - mi[k];
+            acc[k] += di * dj;
+        }
+    }
+    if (!live) return;
+    const double denom = (double)(len - 1);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = i0 + k;
+        if (i < P) s.cov[((size_t)c * P + i) * P + j] = s.scaling * (acc[k] / denom) + (i == j ? s.reg_eps : 0.0);
+    }
+}
+
+// Lower Cholesky factor of cov (+ diag_add on the diagonal), one workgroup per chain, factor built in
+// LDS.  on_failure: 0 = leave chol untouched ("kept only on success"), 1 = 0.1 I (:242-244).
+__global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s, const double diag_add, const int on_failure) {
+    extern __shared__ double L[];  // P x P row-major
+    __shared__ int ok;
+    const int c = blockIdx.x, P = s.P, tid = threadIdx.x;
+    const double* A = s.cov + (size_t)c * P * P;
+    for (int e = tid; e < P * P; e += WAVE) L[e] = 0.0;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    for (int j = 0; j < P; ++j) {
+        if (tid == (j % WAVE)) {
+            double d = A[(size_t)j * P + j] + diag_add;
+            for (int k = 0; k < j; ++k) d -= L[j * P + k] * L[j * P + k];
+            if (!(d > 0.0)) ok = 0;
+            else L[j * P + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (!ok) break;
+        const double ljj = L[j * P + j];
+        for (int i = j + 1 + tid; i < P; i += WAVE) {
+            double v = A[(size_t)i * P + j];
+            for (int k = 0; k < j; ++k) v -= L[i * P + k] * L[j * P + k];
+            L[i * P + j] = v / ljj;
+        }
+        __syncthreads();
+    }
+    double* dst = s.chol + (size_t)c * P * P;
+    if (ok) {
+        for (int e = tid; e < P * P; e += WAVE) dst[e] = L[e];
+    } else if (on_failure == 1) {
+        for (int e = tid; e < P * P; e += WAVE) dst[e] = (e / P == e % P) ? 0.1 : 0.0;
+    }
+}
+
+}  // namespace
+
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream) {
+    hipLaunchKernelGGL(mh_propose_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, pb, d_z, d_scale);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream) {
+    hipLaunchKernelGGL(mh_commit_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       s, d_accept, row);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mh_rank1_cov_kernel, dim3(blocks_for((size_t)s.C * s.P * s.P, 256)), dim3(256), 0, st, s, gamma, last_row);
+    hipLaunchKernelGGL(mh_rank1_mean_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, st, s, gamma, last_row);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_full_covariance(const SamplerState& s, int len, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mh_full_mean_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, st, s, len);
+    hipLaunchKernelGGL(mh_full_cov_kernel, dim3(s.C, (s.P + IT - 1) / IT, (s.P + WAVE - 1) / WAVE), dim3(WAVE), 0, st, s, len);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream) {
+    const size_t lds = (size_t)s.P * s.P * sizeof(double);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mh_cholesky_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return -3;
+    hipLaunchKernelGGL(mh_cholesky_kernel, dim3(s.C), dim3(WAVE), lds, static_cast<hipStream_t>(stream), s, diag_add, on_failure);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace sepaihrd

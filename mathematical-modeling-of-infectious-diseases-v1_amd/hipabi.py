@@ -59,7 +59,9 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
     "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
-    "sepaihrd_ensemble_quantiles",
+    "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
+    "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
+    "sepaihrd_mh_read_covariance", "sepaihrd_mh_read_proposal", "sepaihrd_mh_history_length",
 )
 
 _lib = None
@@ -103,6 +105,19 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_reserve.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_timing.argtypes = [vp, C.c_int]
     lib.sepaihrd_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.sepaihrd_mh_create.restype = vp
+    lib.sepaihrd_mh_create.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double]
+    lib.sepaihrd_mh_destroy.restype = None
+    lib.sepaihrd_mh_destroy.argtypes = [vp]
+    lib.sepaihrd_mh_evaluate_current.argtypes = [vp, vp, vp]
+    lib.sepaihrd_mh_propose.argtypes = [vp, vp, vp, vp, vp]
+    lib.sepaihrd_mh_fetch.argtypes = [vp, vp, vp]
+    lib.sepaihrd_mh_commit.argtypes = [vp, vp]
+    lib.sepaihrd_mh_adapt.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    lib.sepaihrd_mh_read_history.argtypes = [vp, vp, C.c_int, vp]
+    lib.sepaihrd_mh_read_covariance.argtypes = [vp, vp]
+    lib.sepaihrd_mh_read_proposal.argtypes = [vp, vp]
+    lib.sepaihrd_mh_history_length.argtypes = [vp]
     lib.sepaihrd_set_initial_state_mode.argtypes = [vp, C.c_int]
     lib.sepaihrd_ensemble_quantiles.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     if path is None:

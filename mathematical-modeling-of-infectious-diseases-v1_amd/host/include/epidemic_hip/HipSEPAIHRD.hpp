@@ -206,6 +206,13 @@ public:
     std::vector<OptimizationResult> optimizeChains(const std::vector<double>& initial, int C,
                                                    IBatchObjectiveFunction& objective,
                                                    IParameterManager& parameterManager);
+    // The same sampler with the per-chain adaptation state (covariance, Cholesky factor, running mean,
+    // chain history) resident on the device: the O(C t P^2) covariance refresh and the C t P doubles of
+    // history stay next to the likelihood kernel, the host keeps the random streams, the accept test and
+    // the scale adaptation.  Same numbers as optimizeChains (strict arithmetic: bit for bit).
+    std::vector<OptimizationResult> optimizeChainsOnDevice(const std::vector<double>& initial, int C,
+                                                           HipSEPAIHRDObjectiveFunction& objective,
+                                                           IParameterManager& parameterManager);
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
 private:
     struct Chain;

@@ -7,9 +7,19 @@
 // proposal_cholesky_, running_mean_, log_scale_/global_scale_, recent_accepts_, chain_history_
 // and its own std::mt19937.  Host work per iteration is O(C P^2) and runs under OpenMP.
 #include "epidemic_hip/HipSEPAIHRD.hpp"
+#include "sepaihrd_hip.h"
+
+#include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace epidemic {
 
@@ -42,6 +52,28 @@ bool cholesky(const std::vector<double>& A, int P, std::vector<double>& L) {
     L.swap(out);
     return true;
 }
+// Host threads for the per-chain loops: the OpenMP default counts every hardware thread of the machine,
+// a container usually owns a share of them (CPU affinity and / or a cgroup quota); oversubscribing the
+// share turns every parallel region into a scheduling storm.  SEPAIHRD_CPU_THREADS overrides.
+int host_thread_share() {
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_max_threads();
+#endif
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64] = {0};
+        double period = 0.0;
+        if (std::fscanf(f, "%63s %lf", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0.0)
+            n = std::min(n, std::max(1, static_cast<int>(std::atof(quota) / period)));
+        std::fclose(f);
+    }
+    if (const char* env = std::getenv("SEPAIHRD_CPU_THREADS")) n = std::max(1, std::min(n, std::atoi(env)));
+    return std::max(1, n);
+}
+
 inline double sanitize(double v) { return (std::isnan(v) || std::isinf(v)) ? -1e18 : v; }  // safeEvaluate :65-74
 }  // namespace
 
@@ -95,6 +127,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
     if (static_cast<int>(initial.size()) != C * P) throw InvalidParameterException("MetropolisHastingsSampler", "initial size != C*P");
     const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
     const size_t PP = static_cast<size_t>(P) * P;
+    const int nthreads = std::min(host_thread_share(), std::max(1, C));
+    (void)nthreads;
 
     std::vector<Chain> chains(static_cast<size_t>(C));
     std::vector<double> batch(static_cast<size_t>(C) * P), values(static_cast<size_t>(C));
@@ -145,7 +179,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
 
     for (int t = 1; t < iterations_; ++t) {
         // ---- 1+2: adaptation and proposal, independent per chain
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Chain& ch = chains[static_cast<size_t>(c)];
             if (t > burn_in_) {
@@ -210,7 +244,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         // ---- 3: one batched evaluation for all chains
         eval(batch.data(), C, values.data());
         // ---- 4-7: accept / reject, scale adaptation, bookkeeping
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Chain& ch = chains[static_cast<size_t>(c)];
             OptimizationResult& r = results[static_cast<size_t>(c)];
@@ -268,6 +302,223 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         for (int i = 0; i < P; ++i)
             for (int j = 0; j < P; ++j) r.finalCovariance(i, j) = ch.cov[static_cast<size_t>(i) * P + j];
         r.additionalStats["acceptance_rate"] = static_cast<double>(ch.accepted) / iterations_;  // :387
+        r.additionalStats["accepted_count"] = ch.accepted;
+        r.additionalStats["final_scale"] = ch.scale;
+        r.additionalStats["burn_in"] = static_cast<double>(burn_in_);
+        r.additionalStats["total_iterations"] = static_cast<double>(iterations_);
+    }
+    return results;
+}
+
+// ------------------------------------------------------------------ device-resident state
+std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDevice(
+    const std::vector<double>& initial, int C, HipSEPAIHRDObjectiveFunction& objective, IParameterManager& pm) {
+    if (auto* spm = dynamic_cast<HipSEPAIHRDParameterManager*>(&pm)) spm->setConstraintMode(ConstraintMode::MCMC_REFLECT);  // :207-209
+    objective.syncDeviceConstraintMode();
+    const int P = static_cast<int>(pm.getParameterCount());
+    if (static_cast<int>(initial.size()) != C * P) throw InvalidParameterException("MetropolisHastingsSampler", "initial size != C*P");
+    const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
+    const size_t PP = static_cast<size_t>(P) * P;
+    const int nthreads = std::min(host_thread_share(), std::max(1, C));
+    (void)nthreads;
+
+    // initial covariance of every chain (:219-237)
+    std::vector<double> cov0;
+    if (initial_cov_.size() == PP) {
+        cov0 = initial_cov_;
+    } else {
+        cov0.assign(PP, 0.0);
+        for (int i = 0; i < P; ++i) {
+            const double s = pm.getSigmaForParamIndex(i);
+            cov0[static_cast<size_t>(i) * P + i] = (s > 0 ? s * s : 1e-6);
+        }
+        for (double& v : cov0) v *= scaling_factor;
+    }
+    for (int i = 0; i < P; ++i) cov0[static_cast<size_t>(i) * P + i] += regularization_epsilon_;
+
+    sepaihrd_ctx* ctx = objective.deviceContext();
+    sepaihrd_mh* mh = sepaihrd_mh_create(ctx, C, std::max(iterations_, 1), initial.data(), cov0.data(), regularization_epsilon_,
+                                         scaling_factor);
+    if (!mh) throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_mh_create: ") + sepaihrd_last_error(ctx));
+    struct Guard { sepaihrd_mh* p; ~Guard() { sepaihrd_mh_destroy(p); } } guard{mh};
+    auto check = [&](int rc, const char* what) {
+        if (rc != SEPAIHRD_OK) throw ModelException("MetropolisHastingsSampler", std::string(what) + ": " + sepaihrd_last_error(ctx));
+    };
+
+    // What the host keeps per chain.  The random stream is consumed in the reference's order: the normals
+    // of a proposal, then ONE uniform only if log_ratio < 0 (:327), then the next proposal's normals.
+    // While the device evaluates proposal t the host prepares the draws of proposal t+1 for BOTH outcomes
+    // of that test (generator copy `with_u` takes the uniform first), and keeps the branch that happened.
+    struct Light {
+        std::mt19937 gen[2];  // gen[cur]: stream without the uniform; gen[1 - cur]: stream that drew it
+        int cur = 0;
+        double u = 0.0;       // the uniform of the branch that draws it
+        double lp = 0.0, log_scale = 0.0, scale = 1.0, best = 0.0;
+        std::vector<unsigned char> recent;  // ring of the last 1000 accept flags (:107-110) + their sum
+        size_t recent_pos = 0, recent_len = 0;
+        int recent_sum = 0;
+        int emergency = 0, accepted = 0;
+        std::vector<double> best_x;
+        std::vector<double> sample_values;
+    };
+    std::vector<Light> chains(static_cast<size_t>(C));
+    const size_t CP = static_cast<size_t>(C) * P;
+    std::vector<double> values(static_cast<size_t>(C)), z(CP), z_no_u(CP), z_with_u(CP), scale(static_cast<size_t>(C)), prop(CP);
+    std::vector<int32_t> status(static_cast<size_t>(C));
+    std::vector<uint8_t> accept(static_cast<size_t>(C));
+    auto sanitize_all = [&]() {
+        for (int c = 0; c < C; ++c)
+            values[static_cast<size_t>(c)] = status[static_cast<size_t>(c)] >= 2 ? -1e18 : sanitize(values[static_cast<size_t>(c)]);
+    };
+    check(sepaihrd_mh_evaluate_current(mh, values.data(), status.data()), "mh_evaluate_current");  // :257
+    sanitize_all();
+    traces_.assign(static_cast<size_t>(C), {});
+    std::vector<int32_t> sample_rows;
+    if (store_samples_) sample_rows.push_back(0);
+    auto draw_normals = [P](std::mt19937& g, double* dst) {  // generateProposal :91-102: a fresh distribution per proposal
+        std::normal_distribution<double> dist(0.0, 1.0);
+        for (int i = 0; i < P; ++i) dst[i] = dist(g);
+    };
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int c = 0; c < C; ++c) {
+        Light& ch = chains[static_cast<size_t>(c)];
+        ch.gen[0].seed(seed_ + static_cast<uint32_t>(c));
+        ch.lp = ch.best = values[static_cast<size_t>(c)];
+        ch.best_x.assign(initial.begin() + static_cast<size_t>(c) * P, initial.begin() + static_cast<size_t>(c + 1) * P);
+        ch.recent.assign(1000, 0);
+        if (store_samples_) ch.sample_values.push_back(ch.lp);
+        traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
+        draw_normals(ch.gen[0], &z[static_cast<size_t>(c) * P]);  // proposal 1
+        scale[static_cast<size_t>(c)] = ch.scale;
+    }
+
+    const bool profile = std::getenv("SEPAIHRD_MH_PROFILE") != nullptr;
+    double t_launch = 0, t_spec = 0, t_wait = 0, t_acc = 0, t_commit = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    for (int t = 1; t < iterations_; ++t) {
+        const auto p0 = now();
+        if (t > burn_in_) {  // :279-301; the history holds t rows (states 0 .. t-1)
+            const bool refresh = (t % adaptation_period_ == 0);
+            check(sepaihrd_mh_adapt(mh, 10.0 / (t + 100.0), refresh ? 1 : 0, static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 1 : 0),
+                  "mh_adapt");
+        }
+        check(sepaihrd_mh_propose(mh, z.data(), scale.data(), nullptr, nullptr), "mh_propose");  // launch only
+        const auto p1 = now();
+        const bool more = t + 1 < iterations_;
+        if (more) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+            for (int c = 0; c < C; ++c) {  // draws of proposal t+1 for both outcomes of this iteration's accept test
+                Light& ch = chains[static_cast<size_t>(c)];
+                std::mt19937& no_u = ch.gen[ch.cur];
+                std::mt19937& with_u = ch.gen[1 - ch.cur];
+                with_u = no_u;
+                std::uniform_real_distribution<double> u_dist(0.0, 1.0);
+                ch.u = u_dist(with_u);
+                draw_normals(no_u, &z_no_u[static_cast<size_t>(c) * P]);
+                draw_normals(with_u, &z_with_u[static_cast<size_t>(c) * P]);
+            }
+        }
+        const auto p2 = now();
+        check(sepaihrd_mh_fetch(mh, values.data(), status.data()), "mh_fetch");
+        sanitize_all();
+        const auto p3 = now();
+        bool any_best = false;
+#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(|| : any_best)
+        for (int c = 0; c < C; ++c) {
+            Light& ch = chains[static_cast<size_t>(c)];
+            const double prop_lp = values[static_cast<size_t>(c)];
+            const double log_ratio = prop_lp - ch.lp;
+            bool acc = false;
+            if (log_ratio >= 0.0) {
+                acc = true;
+                if (more) std::copy_n(&z_no_u[static_cast<size_t>(c) * P], P, &z[static_cast<size_t>(c) * P]);
+            } else {
+                double u = ch.u;
+                if (!more) {  // no speculation ran for the last iteration
+                    std::uniform_real_distribution<double> u_dist(0.0, 1.0);
+                    u = u_dist(ch.gen[ch.cur]);
+                } else {
+                    ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one
+                    std::copy_n(&z_with_u[static_cast<size_t>(c) * P], P, &z[static_cast<size_t>(c) * P]);
+                }
+                if (std::log(u) < log_ratio) acc = true;
+            }
+            accept[static_cast<size_t>(c)] = acc ? 1 : 0;
+            if (acc) {
+                ch.lp = prop_lp;
+                ch.accepted++;
+                if (ch.lp > ch.best) { ch.best = ch.lp; ch.best_x.clear(); any_best = true; }  // filled below
+            }
+            traces_[static_cast<size_t>(c)].push_back(acc ? 1 : 0);
+            if (adapt_scale_) {  // adaptGlobalScale :104-152
+                if (ch.recent_len == 1000) ch.recent_sum -= ch.recent[ch.recent_pos]; else ch.recent_len++;
+                ch.recent[ch.recent_pos] = acc ? 1 : 0;
+                ch.recent_sum += acc ? 1 : 0;
+                ch.recent_pos = (ch.recent_pos + 1) % 1000;
+                const double rate = static_cast<double>(ch.recent_sum) / ch.recent_len;
+                if (ch.recent_len >= 1000 && rate < 0.001) { ch.log_scale -= 0.7; ch.emergency++; }
+                else if (rate < 0.02 && ch.recent_len >= 500) {
+                    double g = 5.0 / std::sqrt(static_cast<double>(t) + 1.0);
+                    g = std::min(g, 0.3);
+                    ch.log_scale += g * (0.0 - target_acceptance_rate_);
+                } else {
+                    double g = 1.0 / std::sqrt(static_cast<double>(t) + 1.0);
+                    g = std::min(g, 0.1);
+                    ch.log_scale += g * ((acc ? 1.0 : 0.0) - target_acceptance_rate_);
+                }
+                if (ch.scale <= 0.011 && rate > 0.15 && rate < 0.30) ch.log_scale += 0.01;
+                ch.log_scale = std::max(std::min(ch.log_scale, 2.3), -6.9);
+                ch.scale = std::exp(ch.log_scale);
+            }
+            scale[static_cast<size_t>(c)] = ch.scale;
+            if (store_samples_ && (t % thinning_ == 0)) ch.sample_values.push_back(ch.lp);
+        }
+        if (any_best) {  // a chain improved its best state: fetch the proposals once
+            check(sepaihrd_mh_read_proposal(mh, prop.data()), "mh_read_proposal");
+            for (int c = 0; c < C; ++c) {
+                Light& ch = chains[static_cast<size_t>(c)];
+                if (ch.best_x.empty())
+                    ch.best_x.assign(prop.begin() + static_cast<size_t>(c) * P, prop.begin() + static_cast<size_t>(c + 1) * P);
+            }
+        }
+        const auto p4 = now();
+        check(sepaihrd_mh_commit(mh, accept.data()), "mh_commit");
+        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
+        const auto p5 = now();
+        t_launch += secs(p0, p1); t_spec += secs(p1, p2); t_wait += secs(p2, p3); t_acc += secs(p3, p4); t_commit += secs(p4, p5);
+    }
+    if (profile)
+        std::fprintf(stderr, "[mh profile] per iteration ms: copies+launch %.3f  draws for t+1 (overlapped) %.3f  wait for device %.3f  accept %.3f  commit %.3f\n",
+                     1e3 * t_launch / iterations_, 1e3 * t_spec / iterations_, 1e3 * t_wait / iterations_, 1e3 * t_acc / iterations_,
+                     1e3 * t_commit / iterations_);
+
+    std::vector<double> rows, covs(static_cast<size_t>(C) * PP);
+    const int ns = static_cast<int>(sample_rows.size());
+    if (ns > 0) {
+        rows.resize(static_cast<size_t>(C) * ns * P);
+        check(sepaihrd_mh_read_history(mh, sample_rows.data(), ns, rows.data()), "mh_read_history");
+    }
+    check(sepaihrd_mh_read_covariance(mh, covs.data()), "mh_read_covariance");
+    std::vector<OptimizationResult> results(static_cast<size_t>(C));
+    for (int c = 0; c < C; ++c) {
+        Light& ch = chains[static_cast<size_t>(c)];
+        OptimizationResult& r = results[static_cast<size_t>(c)];
+        r.bestParameters = Eigen::VectorXd(P);
+        for (int i = 0; i < P; ++i) r.bestParameters[i] = ch.best_x[static_cast<size_t>(i)];
+        r.bestObjectiveValue = ch.best;
+        for (int s = 0; s < ns; ++s) {
+            Eigen::VectorXd v(P);
+            for (int i = 0; i < P; ++i) v[i] = rows[(static_cast<size_t>(c) * ns + s) * P + i];
+            r.samples.push_back(v);
+        }
+        r.sampleObjectiveValues = ch.sample_values;
+        r.finalCovariance = Eigen::MatrixXd(P, P);
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j) r.finalCovariance(i, j) = covs[static_cast<size_t>(c) * PP + static_cast<size_t>(i) * P + j];
+        r.additionalStats["acceptance_rate"] = static_cast<double>(ch.accepted) / iterations_;
         r.additionalStats["accepted_count"] = ch.accepted;
         r.additionalStats["final_scale"] = ch.scale;
         r.additionalStats["burn_in"] = static_cast<double>(burn_in_);

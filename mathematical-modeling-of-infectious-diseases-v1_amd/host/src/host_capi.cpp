@@ -222,7 +222,7 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                       {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0}});
         mh.setSeed(seed);
         std::vector<OptimizationResult> res;
-        if (use_scalar_interface) {
+        if (use_scalar_interface == 1) {
             for (int c = 0; c < C; ++c) {
                 mh.setSeed(seed + static_cast<uint32_t>(c));
                 res.push_back(mh.optimize(vec(initial + static_cast<size_t>(c) * P, P), *h->obj, *h->pm));
@@ -231,7 +231,9 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                               accept_trace + static_cast<size_t>(c) * (iterations - 1));
             }
         } else {
-            res = mh.optimizeChains(std::vector<double>(initial, initial + static_cast<size_t>(C) * P), C, *h->obj, *h->pm);
+            const std::vector<double> init(initial, initial + static_cast<size_t>(C) * P);
+            res = use_scalar_interface == 2 ? mh.optimizeChainsOnDevice(init, C, *h->obj, *h->pm)  // device-resident state
+                                            : mh.optimizeChains(init, C, *h->obj, *h->pm);
             if (accept_trace)
                 for (int c = 0; c < C; ++c)
                     std::copy(mh.acceptTraces()[static_cast<size_t>(c)].begin(), mh.acceptTraces()[static_cast<size_t>(c)].end(),

@@ -181,7 +181,7 @@ class HostObjective:
 
     def metropolis_hastings(self, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
                             thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
-                            adapt_scale: bool = True, scalar_interface: bool = False) -> dict:
+                            adapt_scale: bool = True, scalar_interface: bool = False, device_state: bool = False) -> dict:
         x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
         Cn, P = x0.shape
         cap = iterations // max(1, thinning) + 2
@@ -198,7 +198,8 @@ class HostObjective:
         samples = np.zeros((Cn, n_s, P))
         values = np.zeros((Cn, n_s))
         rc = self.lib.host_mh_run(self.h, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning,
-                                  reg_eps, target_acc, int(adapt_scale), int(scalar_interface), accepted.ctypes.data,
+                                  reg_eps, target_acc, int(adapt_scale), 2 if device_state else int(scalar_interface),
+                                  accepted.ctypes.data,
                                   best_value.ctypes.data, best.ctypes.data, final_scale.ctypes.data,
                                   trace.ctypes.data, C.byref(ns), samples.ctypes.data, values.ctypes.data)
         if rc:

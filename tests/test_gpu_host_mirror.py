@@ -175,3 +175,21 @@ def test_finite_difference_gradient_row_mismatch_follows_the_reference(mm, oracl
     got_v, got_g = mm.HostObjective(pb).evaluate_with_gradient(theta)
     np.testing.assert_allclose(got_v, ref_v, rtol=1e-11)
     assert np.array_equal(got_g, ref_g) and np.all(np.isneginf(ref_g))
+
+
+def test_device_resident_sampler_state_matches_host_loop(mm, oracle_py, shipped):
+    """optimizeChainsOnDevice (covariance, Cholesky factor, running mean and history in HBM; rank-one
+    updates, two-pass refresh and factorisation as kernels) gives the numbers of the host loop bit for
+    bit, and chain 0's accept trace is the oracle's."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    C, iters, burn, ap = 6, 260, 60, 40   # refresh at t = 80, 120, ... with >= P + 10 = 72 states in the history
+    x0 = oracle_py.Oracle(pb).jitter_draws(pb.base_theta, 3, C, mode=1)
+    kw = dict(seed=17, iterations=iters, burn_in=burn, adaptation_period=ap, thinning=5)
+    host = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
+    assert np.array_equal(dev["accept_trace"], host["accept_trace"])
+    assert 0 < host["accept_trace"].sum() < host["accept_trace"].size
+    for k in ("accepted", "best_value", "best", "final_scale", "samples", "sample_values"):
+        assert np.array_equal(dev[k], host[k]), k
+    ref = oracle_py.Oracle(pb).metropolis_hastings(x0[0], 17, iters, burn, adaptation_period=ap, thinning=5)
+    assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"])
