@@ -122,7 +122,7 @@ void HipModelCalibrator::calibrate(const std::map<std::string, double>& phase1_s
     std::vector<double> init(static_cast<size_t>(C) * P);
     for (int c = 0; c < C; ++c)
         for (int i = 0; i < P; ++i) init[static_cast<size_t>(c) * P + i] = best_[i];
-    phase2_ = mh.optimizeChains(init, C, obj_, pm_);
+    phase2_ = mh.optimizeChainsOnDevice(init, C, obj_, pm_);  // sampler state resident in HBM, same numbers
     traces_ = mh.acceptTraces();
     for (const OptimizationResult& r : phase2_)
         if (r.bestObjectiveValue > best_value_) {
