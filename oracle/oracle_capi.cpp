@@ -306,6 +306,35 @@ int oracle_condition_covariance(void* hv, const double* cov, double* out) {
     return 0;
 }
 
+namespace {
+oracle::SIRParams sir_params(int n, const double* N, const double* C, const double* gamma, double q, double scale_C) {
+    oracle::SIRParams p;
+    p.n = n; p.q = q; p.scale_C = scale_C;
+    p.N.assign(N, N + n); p.C.assign(C, C + n * n); p.gamma.assign(gamma, gamma + n);
+    return p;
+}
+}  // namespace
+
+void oracle_sir_rhs(int n, const double* N, const double* C, const double* gamma, double q, double scale_C,
+                    const double* state, double* deriv) {
+    oracle::sir_rhs(sir_params(n, N, C, gamma, q, scale_C), state, deriv);
+}
+
+int oracle_sir_simulate(int n, const double* N, const double* C, const double* gamma, double q, double scale_C,
+                        const double* init, const double* times, int n_times, double abs_err, double rel_err,
+                        double* traj, int32_t* n_accept, int32_t* n_reject) {
+    try {
+        oracle::StepStats st;
+        const std::vector<double> flat = oracle::sir_simulate(sir_params(n, N, C, gamma, q, scale_C),
+                                                              oracle::state_type(init, init + 3 * n),
+                                                              std::vector<double>(times, times + n_times), abs_err, rel_err, &st);
+        std::copy(flat.begin(), flat.end(), traj);
+        if (n_accept) *n_accept = static_cast<int32_t>(st.accepted);
+        if (n_reject) *n_reject = static_cast<int32_t>(st.rejected);
+        return 0;
+    } catch (const std::exception&) { return 2; }
+}
+
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t* out) {
     const std::vector<int> sel = oracle::select_ppc_samples(static_cast<size_t>(n_samples), num_for_ppc, seed);
     std::copy(sel.begin(), sel.end(), out);

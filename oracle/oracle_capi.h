@@ -68,6 +68,12 @@ int oracle_calibrate(void *h, int hc_iterations, int cloud_size_multiplier, int 
                      double *samples, double *sample_values, double *mcmc_objective_values, int32_t *n_samples);
 /* ModelCalibrator.cpp:93-131 on a given covariance (row-major P x P) with the handle's sigmas */
 int oracle_condition_covariance(void *h, const double *cov, double *out);
+/* BASELINE config 0 plumbing (CPU only): AgeSIRModel RHS and a Dopri5 run.  C row-major n x n, state [S,I,R] x n. */
+void oracle_sir_rhs(int n, const double *N, const double *C, const double *gamma, double q, double scale_C,
+                    const double *state, double *deriv);
+int oracle_sir_simulate(int n, const double *N, const double *C, const double *gamma, double q, double scale_C,
+                        const double *init, const double *times, int n_times, double abs_err, double rel_err,
+                        double *traj, int32_t *n_accept, int32_t *n_reject);
 /* returns the number of indices written (ResultAggregator.cpp:246-266) */
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t *out);
 int oracle_num_threads(void);

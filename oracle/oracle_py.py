@@ -74,6 +74,10 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_condition_covariance.argtypes = [vp, vp, vp]
+    lib.oracle_sir_rhs.restype = None
+    lib.oracle_sir_rhs.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    lib.oracle_sir_simulate.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, C.c_int, C.c_double,
+                                        C.c_double, vp, vp, vp]
     lib.oracle_ppc_select.argtypes = [C.c_int, C.c_int, C.c_uint32, vp]
     lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
@@ -275,6 +279,27 @@ class Oracle:
         return {"best": best, "best_value": best_value.value, "accepted": accepted.value,
                 "final_scale": final_scale.value, "accept_trace": trace[:iterations - 1],
                 "samples": samples[:ns], "sample_values": values[:ns], "final_cov": cov}
+
+
+def sir_rhs(N, Cm, gamma, q, scale_C, state) -> np.ndarray:
+    """AgeSIRModel::computeDerivatives (BASELINE config 0 plumbing)."""
+    N, Cm, gamma, state = (np.ascontiguousarray(a, dtype=np.float64) for a in (N, Cm, gamma, state))
+    out = np.empty_like(state)
+    load().oracle_sir_rhs(len(N), N.ctypes.data, Cm.ctypes.data, gamma.ctypes.data, q, scale_C, state.ctypes.data,
+                          out.ctypes.data)
+    return out
+
+
+def sir_simulate(N, Cm, gamma, q, scale_C, init, times, abs_err=1e-6, rel_err=1e-6) -> dict:
+    N, Cm, gamma, init, times = (np.ascontiguousarray(a, dtype=np.float64) for a in (N, Cm, gamma, init, times))
+    traj = np.empty((len(times), init.size))
+    na, nr = C.c_int32(0), C.c_int32(0)
+    rc = load().oracle_sir_simulate(len(N), N.ctypes.data, Cm.ctypes.data, gamma.ctypes.data, q, scale_C, init.ctypes.data,
+                                    times.ctypes.data, len(times), abs_err, rel_err, traj.ctypes.data, C.byref(na),
+                                    C.byref(nr))
+    if rc != 0:
+        raise RuntimeError("sir_simulate failed")
+    return {"traj": traj, "n_accept": na.value, "n_reject": nr.value}
 
 
 def ppc_select(n_samples: int, num_for_ppc: int, seed: int) -> np.ndarray:

@@ -1500,4 +1500,51 @@ inline CalibrationResult calibrate(const HCSettings& hc_cfg, MHSettings mh_cfg, 
     return r;
 }
 
+// -----------------------------------------------------------------------------
+// BASELINE config 0 ("plumbing", CPU only): the age-structured SIR model behind the same interfaces,
+// AgeSIRModel::computeDerivatives (src/sir_age_structured/AgeSIRModel.cpp:106-139):
+//   lambda = q (C_current (I / N)) with I/N = 0 where N <= 1e-9, clipped at 0; dS = -lambda S,
+//   dI = lambda S - gamma I, dR = gamma I; a negative derivative of a compartment below 1e-9 is zeroed.
+// C_current = baseline contact matrix * scale (:97-103).  State layout [S(n), I(n), R(n)].
+// The reference has NO fixed-step RK4 strategy (BASELINE config 0 names one): the run goes through the
+// same controlled Dopri5 / integrate_times restatement as the SEPAIHRD path.
+// -----------------------------------------------------------------------------
+struct SIRParams {
+    int n = 0;
+    std::vector<double> N, C, gamma;  // C row-major n x n (baseline), gamma per age
+    double q = 0.0, scale_C = 1.0;
+};
+
+inline void sir_rhs(const SIRParams& p, const double* x, double* dx) {
+    const int n = p.n;
+    std::vector<double> ion(n, 0.0);
+    for (int j = 0; j < n; ++j)
+        if (p.N[j] > 1e-9) ion[j] = x[n + j] / p.N[j];
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += (p.C[i * n + j] * p.scale_C) * ion[j];
+        double lambda = p.q * acc;
+        lambda = std::max(lambda, 0.0);
+        const double S = x[i], I = x[n + i], R = x[2 * n + i];
+        double dS = -lambda * S, dI = lambda * S - p.gamma[i] * I, dR = p.gamma[i] * I;
+        if (S < 1e-9 && dS < 0) dS = 0.0;
+        if (I < 1e-9 && dI < 0) dI = 0.0;
+        if (R < 1e-9 && dR < 0) dR = 0.0;
+        dx[i] = dS; dx[n + i] = dI; dx[2 * n + i] = dR;
+    }
+}
+
+// trajectory [T][3n] at the output times, Dopri5 via the same integrate_times restatement
+inline std::vector<double> sir_simulate(const SIRParams& p, const state_type& init, const std::vector<double>& times,
+                                        double abs_err, double rel_err, StepStats* stats = nullptr) {
+    System sys = [&p](const double* xs, double* dx, double) { sir_rhs(p, xs, dx); };
+    std::vector<double> flat;
+    flat.reserve(times.size() * init.size());
+    auto obs = [&flat](const state_type& x, double) { flat.insert(flat.end(), x.begin(), x.end()); };
+    state_type x = init;
+    ControlledDopri5 stepper(abs_err, rel_err, stats);
+    integrate_times(stepper, sys, x, times, 1.0, obs, stats ? stats->max_attempts : 1000000);
+    return flat;
+}
+
 }  // namespace oracle
