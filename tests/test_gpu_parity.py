@@ -181,3 +181,50 @@ def test_other_age_class_counts(mm, oracle_py, shipped, n_age, solver):
     assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
     assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
     np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("arith", ["strict", "fma"])
+@pytest.mark.parametrize("solver,B", [(0, 20000), (0, 32768 + 37), (1, 20000), (1, 32768 + 37)])
+def test_saturating_batches_use_the_same_arithmetic(mm, oracle_py, synth400, draws, solver, B, arith):
+    """BASELINE config 3 / 4 sizes per GPU (and config 3's Cash-Karp): batches of more than 1024 waves run
+    the inline-likelihood kernel (Cash-Karp from 2048 waves on: its two-waves-per-SIMD build).  The same
+    chains evaluated in chunks of 4096 (separate likelihood pass, one wave per SIMD) must give the SAME
+    bits -- log-likelihood, status and step counts -- and a sample of them is checked against the oracle."""
+    pb = synth400.with_(solver=solver, arith=mm.ARITH_STRICT if arith == "strict" else mm.ARITH_FMA)
+    base = draws(pb, 4096)
+    theta = np.tile(base, ((B + 4095) // 4096, 1))[:B]
+    hip = mm.HipObjective(pb)
+    big = hip.eval_batch(theta)
+    assert np.all(big["status"] == 0)
+    for off in range(0, B, 4096):
+        part = hip.eval_batch(theta[off:off + 4096])
+        for k in ("loglik", "status", "n_accept", "n_reject"):
+            assert np.array_equal(part[k], big[k][off:off + 4096]), (k, off)
+    if arith == "strict":
+        idx = np.linspace(0, B - 1, 24).astype(int)
+        ref = oracle_py.Oracle(pb).eval_batch(theta[idx])
+        assert np.array_equal(big["n_accept"][idx], ref["n_accept"]) and np.array_equal(big["n_reject"][idx], ref["n_reject"])
+        np.testing.assert_allclose(big["loglik"][idx], ref["loglik"], rtol=1e-10)
+
+
+def test_sixteen_age_classes_saturating_batch(mm, oracle_py, shipped):
+    """BASELINE config 5's lane layout (16 lanes per chain, 4 chains per wave) in a batch of more than
+    1024 waves: inline-likelihood kernel == chunks through the separate pass == oracle on a sample."""
+    from mmid_amd import draws as dr
+    pb = mm.widen_age_classes(shipped, 4)
+    pb.arith = mm.ARITH_STRICT
+    pb.times = pb.times[:80]
+    pb = pb.with_(obs_H=pb.obs_H[:60], obs_ICU=pb.obs_ICU[:60], obs_D=pb.obs_D[:60])
+    B = 4 * 1100 + 3
+    theta = np.tile(dr.jitter_draws(pb, 5, 512), (B // 512 + 1, 1))[:B]
+    hip = mm.HipObjective(pb)
+    big = hip.eval_batch(theta)
+    assert np.all(big["status"] == 0)
+    for off in range(0, B, 2048):
+        part = hip.eval_batch(theta[off:off + 2048])
+        for k in ("loglik", "n_accept", "n_reject"):
+            assert np.array_equal(part[k], big[k][off:off + 2048]), (k, off)
+    idx = np.linspace(0, B - 1, 12).astype(int)
+    ref = oracle_py.Oracle(pb).eval_batch(theta[idx])
+    assert np.array_equal(big["n_accept"][idx], ref["n_accept"])
+    np.testing.assert_allclose(big["loglik"][idx], ref["loglik"], rtol=1e-10)
