@@ -43,6 +43,8 @@ def parse_args():
                          "tolerance); strict: the CPU build's operation sequence (bit-level parity mode)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
+    ap.add_argument("--sampler-iterations", type=int, default=400,
+                    help="informational Adaptive-Metropolis run around the kernel after the timed region (0 = skip)")
     return ap.parse_args()
 
 
@@ -102,6 +104,26 @@ def cpu_baseline(pb, theta, budget_s):
                   f"OpenMP over chains on {cores} threads; single thread: {n1 / dt1:.1f} evals/s",
         "single_thread_value": n1 / dt1,
     }
+
+
+def sampler_pipeline(mm, pb, theta, iterations=None):
+    """Informational, outside the timed region: the whole Adaptive-Metropolis iteration around the kernel
+    (host random streams + accept test, device-resident proposal / adaptation state, one evaluation per
+    chain and iteration), proposals per second for the step's chains.  None if the host library is absent."""
+    try:
+        iters = int(iterations or 120)
+        host = mm.HostObjective(pb)
+        host.metropolis_hastings(theta[:16], 1, 4, 1, device_state=True)
+        t0 = time.perf_counter()
+        r = host.metropolis_hastings(theta, 1, iters, iters // 3, adaptation_period=max(10, iters // 4), thinning=iters,
+                                     device_state=True)
+        dt = time.perf_counter() - t0
+        return {"proposals_per_s": theta.shape[0] * (iters - 1) / dt, "ms_per_iteration": dt / (iters - 1) * 1e3,
+                "chains": int(theta.shape[0]), "iterations": iters,
+                "acceptance": float(r["accepted"].mean() / (iters - 1)),
+                "note": "includes setup and read-back of the run; sampler state resident in HBM (DESIGN.md 6c)"}
+    except Exception as e:  # informational only
+        return {"error": str(e)[:200]}
 
 
 def main():
@@ -277,6 +299,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pb, pools_host[0], args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        out["sampler_pipeline"] = sampler_pipeline(mm, pb, pools_host[0], args.sampler_iterations) if world == 1 and args.sampler_iterations > 1 else None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
