@@ -670,6 +670,7 @@ struct sepaihrd_mh {
     sepaihrd_ctx* ctx = nullptr;
     SamplerState st{};
     int rows = 0;  // history rows written so far
+    hipStream_t stream = nullptr;  // own non-blocking stream: several samplers (one per host thread) overlap
     double* d_z = nullptr;
     double* d_scale = nullptr;
     double* d_loglik = nullptr;
@@ -685,11 +686,13 @@ namespace {
 int mh_eval(sepaihrd_mh* mh, const double* d_theta, double* loglik, int32_t* status) {
     sepaihrd_ctx* ctx = mh->ctx;
     const int C = mh->st.C;
-    const int rc = sepaihrd_eval_batch_device(ctx, d_theta, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const int rc = sepaihrd_eval_batch_device(ctx, d_theta, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, mh->stream);
     if (rc != SEPAIHRD_OK) return rc;
-    HIP_TRY(hipMemcpy(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, mh->stream), ctx, return SEPAIHRD_E_HIP);
     if (status)
-        HIP_TRY(hipMemcpy(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMemcpyAsync(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost, mh->stream), ctx,
+                return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
 }
 }  // namespace
@@ -726,19 +729,21 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     dalloc((void**)&mh->d_status, (size_t)C * sizeof(int32_t));
     dalloc((void**)&mh->d_accept, (size_t)C);
     if (ok && sepaihrd_reserve(ctx, C) != SEPAIHRD_OK) ok = false;
+    if (ok && hipStreamCreateWithFlags(&mh->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     if (ok) {
         std::vector<double> cov_all(CPP);
         for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
         ok = hipMemcpy(st.x, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(st.mean, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(st.cov, cov_all.data(), CPP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemset(st.chol, 0, CPP * sizeof(double)) == hipSuccess;
+             hipMemsetAsync(st.chol, 0, CPP * sizeof(double), mh->stream) == hipSuccess;
     }
-    if (ok) ok = sampler_cholesky(st, 0.0, 1, nullptr) == 0 && sampler_commit(st, nullptr, 0, nullptr) == 0 &&
-                 hipDeviceSynchronize() == hipSuccess;
+    if (ok) ok = sampler_cholesky(st, 0.0, 1, mh->stream) == 0 && sampler_commit(st, nullptr, 0, mh->stream) == 0 &&
+                 hipStreamSynchronize(mh->stream) == hipSuccess;
     if (!ok) {
         ctx->last_error = "mh_create: device allocation or initialisation failed (history = C * capacity * P doubles)";
         for (void* p : mh->allocs) (void)hipFree(p);
+        if (mh->stream) (void)hipStreamDestroy(mh->stream);
         delete mh;
         return nullptr;
     }
@@ -749,6 +754,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
 void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (!mh) return;
     (void)hipSetDevice(mh->ctx->device);
+    if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
     for (void* p : mh->allocs) (void)hipFree(p);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
     if (mh->d_gather) (void)hipFree(mh->d_gather);
@@ -768,15 +774,16 @@ int sepaihrd_mh_propose(sepaihrd_mh* mh, const double* z, const double* scale, d
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const size_t CP = (size_t)mh->st.C * mh->st.P;
-    HIP_TRY(hipMemcpy(mh->d_z, z, CP * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
-    HIP_TRY(hipMemcpy(mh->d_scale, scale, (size_t)mh->st.C * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
-    if (sampler_propose(mh->st, ctx->dp, mh->d_z, mh->d_scale, nullptr) != 0) {
+    HIP_TRY(hipMemcpyAsync(mh->d_z, z, CP * sizeof(double), hipMemcpyHostToDevice, mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(mh->d_scale, scale, (size_t)mh->st.C * sizeof(double), hipMemcpyHostToDevice, mh->stream), ctx,
+            return SEPAIHRD_E_HIP);
+    if (sampler_propose(mh->st, ctx->dp, mh->d_z, mh->d_scale, mh->stream) != 0) {
         ctx->last_error = "mh_propose: launch failed";
         return SEPAIHRD_E_HIP;
     }
     if (!loglik)  // launch only: the caller overlaps host work and calls sepaihrd_mh_fetch
         return sepaihrd_eval_batch_device(ctx, mh->st.prop, mh->st.C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr,
-                                          nullptr);
+                                          mh->stream);
     return mh_eval(mh, mh->st.prop, loglik, status);
 }
 
@@ -785,9 +792,11 @@ int sepaihrd_mh_fetch(sepaihrd_mh* mh, double* loglik, int32_t* status) {
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const int C = mh->st.C;
-    HIP_TRY(hipMemcpy(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, mh->stream), ctx, return SEPAIHRD_E_HIP);
     if (status)
-        HIP_TRY(hipMemcpy(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMemcpyAsync(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost, mh->stream), ctx,
+                return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
 }
 
@@ -799,8 +808,8 @@ int sepaihrd_mh_commit(sepaihrd_mh* mh, const uint8_t* accept) {
         return SEPAIHRD_E_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    HIP_TRY(hipMemcpy(mh->d_accept, accept, (size_t)mh->st.C, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
-    if (sampler_commit(mh->st, mh->d_accept, mh->rows, nullptr) != 0) {
+    HIP_TRY(hipMemcpyAsync(mh->d_accept, accept, (size_t)mh->st.C, hipMemcpyHostToDevice, mh->stream), ctx, return SEPAIHRD_E_HIP);
+    if (sampler_commit(mh->st, mh->d_accept, mh->rows, mh->stream) != 0) {
         ctx->last_error = "mh_commit: launch failed";
         return SEPAIHRD_E_HIP;
     }
@@ -812,13 +821,13 @@ int sepaihrd_mh_adapt(sepaihrd_mh* mh, double gamma, int refresh, int recompute_
     if (!mh) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    int rc = sampler_rank1(mh->st, gamma, mh->rows - 1, nullptr);
+    int rc = sampler_rank1(mh->st, gamma, mh->rows - 1, mh->stream);
     if (rc == 0 && refresh) {
         if (recompute_full) {
-            rc = sampler_full_covariance(mh->st, mh->rows, nullptr);
-            if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, nullptr);  // :190-197, kept on success
+            rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
+            if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, mh->stream);  // :190-197, kept on success
         }
-        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, nullptr);  // :295-300
+        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);  // :295-300
     }
     if (rc != 0) {
         ctx->last_error = "mh_adapt: launch failed";
@@ -837,7 +846,7 @@ int sepaihrd_mh_read_history(sepaihrd_mh* mh, const int32_t* rows, int n_rows, d
             ctx->last_error = "mh_read_history: row out of range";
             return SEPAIHRD_E_INVALID_ARG;
         }
-    HIP_TRY(hipDeviceSynchronize(), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     // strided copies straight out of the history: row r of every chain = a 2-D region
     for (int r = 0; r < n_rows; ++r)
         HIP_TRY(hipMemcpy2D(out + (size_t)r * P, (size_t)n_rows * P * sizeof(double),
@@ -851,6 +860,7 @@ int sepaihrd_mh_read_proposal(sepaihrd_mh* mh, double* prop) {
     if (!mh || !prop) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpy(prop, mh->st.prop, (size_t)mh->st.C * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
             return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
@@ -860,6 +870,7 @@ int sepaihrd_mh_read_covariance(sepaihrd_mh* mh, double* cov) {
     if (!mh || !cov) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpy(cov, mh->st.cov, (size_t)mh->st.C * mh->st.P * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
             return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;

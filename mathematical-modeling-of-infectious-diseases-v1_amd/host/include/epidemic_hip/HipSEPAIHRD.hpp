@@ -213,6 +213,15 @@ public:
     std::vector<OptimizationResult> optimizeChainsOnDevice(const std::vector<double>& initial, int C,
                                                            HipSEPAIHRDObjectiveFunction& objective,
                                                            IParameterManager& parameterManager);
+    // optimizeChainsOnDevice for G = objectives.size() contiguous groups of chains, one host thread, one
+    // device context and one stream per group: while one group waits for its evaluation the others draw,
+    // decide and launch, so the device sees several evaluations in flight (a batch of a few thousand chains
+    // leaves most SIMDs idle).  Chain c draws from mt19937(seed + c) whatever the grouping:
+    // the results are those of one group.
+    std::vector<OptimizationResult> optimizeChainGroupsOnDevice(const std::vector<double>& initial, int C,
+                                                                const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives,
+                                                                IParameterManager& parameterManager);
+    void setHostThreads(int n) { host_threads_ = n; }  // per-run cap on the OpenMP team (0 = the CPU share)
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
 private:
     struct Chain;
@@ -225,6 +234,7 @@ private:
     uint32_t seed_ = 1;
     std::vector<std::vector<unsigned char>> traces_;
     std::vector<double> initial_cov_;  // row-major P x P, empty = none
+    int host_threads_ = 0;
 };
 
 }  // namespace epidemic

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,7 +128,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
     if (static_cast<int>(initial.size()) != C * P) throw InvalidParameterException("MetropolisHastingsSampler", "initial size != C*P");
     const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
     const size_t PP = static_cast<size_t>(P) * P;
-    const int nthreads = std::min(host_thread_share(), std::max(1, C));
+    const int nthreads = std::min(host_threads_ > 0 ? std::min(host_threads_, host_thread_share()) : host_thread_share(), std::max(1, C));
     (void)nthreads;
 
     std::vector<Chain> chains(static_cast<size_t>(C));
@@ -319,7 +320,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     if (static_cast<int>(initial.size()) != C * P) throw InvalidParameterException("MetropolisHastingsSampler", "initial size != C*P");
     const double scaling_factor = (2.38 * 2.38) / static_cast<double>(P);
     const size_t PP = static_cast<size_t>(P) * P;
-    const int nthreads = std::min(host_thread_share(), std::max(1, C));
+    const int nthreads = std::min(host_threads_ > 0 ? std::min(host_threads_, host_thread_share()) : host_thread_share(), std::max(1, C));
     (void)nthreads;
 
     // initial covariance of every chain (:219-237)
@@ -347,10 +348,11 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 
     // What the host keeps per chain.  The random stream is consumed in the reference's order: the normals
     // of a proposal, then ONE uniform only if log_ratio < 0 (:327), then the next proposal's normals.
-    // While the device evaluates proposal t the host prepares the draws of proposal t+1 for BOTH outcomes
-    // of that test (generator copy `with_u` takes the uniform first), and keeps the branch that happened.
+    // While the device evaluates proposal t the host prepares the draws of proposal t+1 for the likely
+    // outcome of that test (a generator copy takes the uniform first); chains whose test needs no uniform
+    // draw theirs from the untouched stream afterwards.
     struct Light {
-        std::mt19937 gen[2];  // gen[cur]: stream without the uniform; gen[1 - cur]: stream that drew it
+        std::mt19937 gen[2];  // gen[cur]: the chain's stream; gen[1 - cur]: its copy that already drew the uniform
         int cur = 0;
         double u = 0.0;       // the uniform of the branch that draws it
         double lp = 0.0, log_scale = 0.0, scale = 1.0, best = 0.0;
@@ -363,7 +365,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     };
     std::vector<Light> chains(static_cast<size_t>(C));
     const size_t CP = static_cast<size_t>(C) * P;
-    std::vector<double> values(static_cast<size_t>(C)), z(CP), z_no_u(CP), z_with_u(CP), scale(static_cast<size_t>(C)), prop(CP);
+    std::vector<double> values(static_cast<size_t>(C)), z(CP), z_with_u(CP), scale(static_cast<size_t>(C)), prop(CP);
     std::vector<int32_t> status(static_cast<size_t>(C));
     std::vector<uint8_t> accept(static_cast<size_t>(C));
     auto sanitize_all = [&]() {
@@ -410,14 +412,15 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         const bool more = t + 1 < iterations_;
         if (more) {
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-            for (int c = 0; c < C; ++c) {  // draws of proposal t+1 for both outcomes of this iteration's accept test
+            for (int c = 0; c < C; ++c) {
+                // draws of proposal t+1 for the LIKELY outcome of this iteration's accept test (log_ratio < 0:
+                // the uniform is drawn first); the other outcome's draws are made after the test, for the
+                // chains that need them
                 Light& ch = chains[static_cast<size_t>(c)];
-                std::mt19937& no_u = ch.gen[ch.cur];
                 std::mt19937& with_u = ch.gen[1 - ch.cur];
-                with_u = no_u;
+                with_u = ch.gen[ch.cur];
                 std::uniform_real_distribution<double> u_dist(0.0, 1.0);
                 ch.u = u_dist(with_u);
-                draw_normals(no_u, &z_no_u[static_cast<size_t>(c) * P]);
                 draw_normals(with_u, &z_with_u[static_cast<size_t>(c) * P]);
             }
         }
@@ -434,7 +437,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             bool acc = false;
             if (log_ratio >= 0.0) {
                 acc = true;
-                if (more) std::copy_n(&z_no_u[static_cast<size_t>(c) * P], P, &z[static_cast<size_t>(c) * P]);
+                if (more) draw_normals(ch.gen[ch.cur], &z[static_cast<size_t>(c) * P]);  // the stream without the uniform
             } else {
                 double u = ch.u;
                 if (!more) {  // no speculation ran for the last iteration
@@ -523,6 +526,47 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         r.additionalStats["final_scale"] = ch.scale;
         r.additionalStats["burn_in"] = static_cast<double>(burn_in_);
         r.additionalStats["total_iterations"] = static_cast<double>(iterations_);
+    }
+    return results;
+}
+
+std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroupsOnDevice(
+    const std::vector<double>& initial, int C, const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives,
+    IParameterManager& pm) {
+    const int G = static_cast<int>(objectives.size());
+    if (G <= 0) throw InvalidParameterException("MetropolisHastingsSampler", "no objective given");
+    const int P = static_cast<int>(pm.getParameterCount());
+    if (static_cast<int>(initial.size()) != C * P) throw InvalidParameterException("MetropolisHastingsSampler", "initial size != C*P");
+    if (G == 1 || C < G) return optimizeChainsOnDevice(initial, C, *objectives[0], pm);
+    if (auto* spm = dynamic_cast<HipSEPAIHRDParameterManager*>(&pm)) spm->setConstraintMode(ConstraintMode::MCMC_REFLECT);
+    std::vector<int> first(static_cast<size_t>(G) + 1, 0);
+    for (int g = 0; g < G; ++g) first[static_cast<size_t>(g) + 1] = first[static_cast<size_t>(g)] + C / G + (g < C % G ? 1 : 0);
+    const int share = host_threads_ > 0 ? std::min(host_threads_, host_thread_share()) : host_thread_share();
+    std::vector<std::vector<OptimizationResult>> parts(static_cast<size_t>(G));
+    std::vector<std::vector<std::vector<unsigned char>>> part_traces(static_cast<size_t>(G));
+    std::vector<std::string> errors(static_cast<size_t>(G));
+    std::vector<std::thread> workers;
+    for (int g = 0; g < G; ++g) {
+        workers.emplace_back([&, g]() {
+            try {
+                MultiChainMetropolisHastings local = *this;  // settings + initial covariance
+                local.seed_ = seed_ + static_cast<uint32_t>(first[static_cast<size_t>(g)]);
+                local.host_threads_ = std::max(1, share / G);
+                const int c0 = first[static_cast<size_t>(g)], c1 = first[static_cast<size_t>(g) + 1];
+                const std::vector<double> init(initial.begin() + static_cast<size_t>(c0) * P, initial.begin() + static_cast<size_t>(c1) * P);
+                parts[static_cast<size_t>(g)] = local.optimizeChainsOnDevice(init, c1 - c0, *objectives[static_cast<size_t>(g)], pm);
+                part_traces[static_cast<size_t>(g)] = local.traces_;
+            } catch (const std::exception& e) { errors[static_cast<size_t>(g)] = e.what(); }
+        });
+    }
+    for (std::thread& w : workers) w.join();
+    for (const std::string& e : errors)
+        if (!e.empty()) throw ModelException("MetropolisHastingsSampler", e);
+    std::vector<OptimizationResult> results;
+    traces_.clear();
+    for (int g = 0; g < G; ++g) {
+        for (OptimizationResult& r : parts[static_cast<size_t>(g)]) results.push_back(std::move(r));
+        for (auto& t : part_traces[static_cast<size_t>(g)]) traces_.push_back(std::move(t));
     }
     return results;
 }

@@ -367,4 +367,37 @@ int host_gradient(void* hv, const sepaihrd_problem* pb, int device, const double
     }
 }
 
+// optimizeChainGroupsOnDevice over G handles (one device context each; parameter manager of the first).
+// Outputs as host_mh_run, without the samples.
+int host_mh_run_groups(void** handles, int G, int C, const double* initial, uint32_t seed, int iterations, int burn_in,
+                       int adaptation_period, int thinning, int32_t* accepted, double* best_value, double* best,
+                       unsigned char* accept_trace) {
+    try {
+        auto* h0 = static_cast<HostHandle*>(handles[0]);
+        const int P = static_cast<int>(h0->pm->getParameterCount());
+        std::vector<HipSEPAIHRDObjectiveFunction*> objs;
+        for (int g = 0; g < G; ++g) objs.push_back(static_cast<HostHandle*>(handles[g])->obj.get());
+        MultiChainMetropolisHastings mh;
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+                      {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
+                      {"store_samples", 0.0}});
+        mh.setSeed(seed);
+        const std::vector<OptimizationResult> res =
+            mh.optimizeChainGroupsOnDevice(std::vector<double>(initial, initial + static_cast<size_t>(C) * P), C, objs, *h0->pm);
+        for (int c = 0; c < C; ++c) {
+            const OptimizationResult& r = res[static_cast<size_t>(c)];
+            if (accepted) accepted[c] = static_cast<int32_t>(r.additionalStats.at("accepted_count"));
+            if (best_value) best_value[c] = r.bestObjectiveValue;
+            if (best) for (int i = 0; i < P; ++i) best[static_cast<size_t>(c) * P + i] = r.bestParameters[i];
+            if (accept_trace)
+                std::copy(mh.acceptTraces()[static_cast<size_t>(c)].begin(), mh.acceptTraces()[static_cast<size_t>(c)].end(),
+                          accept_trace + static_cast<size_t>(c) * (iterations - 1));
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
 }  // extern "C"

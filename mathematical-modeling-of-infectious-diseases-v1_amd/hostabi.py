@@ -39,6 +39,7 @@ def load_library() -> C.CDLL:
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_mh_run_groups.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.host_gradient.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_double, vp, vp]
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -207,3 +208,23 @@ class HostObjective:
         assert ns.value == n_s
         return {"accepted": accepted, "best_value": best_value, "best": best, "final_scale": final_scale,
                 "accept_trace": trace[:, :iterations - 1], "samples": samples, "sample_values": values}
+
+
+def metropolis_hastings_groups(objectives, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
+                               thinning: int = 1) -> dict:
+    """MultiChainMetropolisHastings::optimizeChainGroupsOnDevice over len(objectives) HostObjective handles
+    (one device context, stream and host thread per group of chains)."""
+    lib = load_library()
+    x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
+    Cn, P = x0.shape
+    G = len(objectives)
+    handles = (C.c_void_p * G)(*[o.h for o in objectives])
+    accepted = np.zeros(Cn, dtype=np.int32)
+    best_value = np.zeros(Cn)
+    best = np.zeros((Cn, P))
+    trace = np.zeros((Cn, max(iterations - 1, 1)), dtype=np.uint8)
+    rc = lib.host_mh_run_groups(handles, G, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning,
+                                accepted.ctypes.data, best_value.ctypes.data, best.ctypes.data, trace.ctypes.data)
+    if rc:
+        raise RuntimeError(lib.host_last_error().decode())
+    return {"accepted": accepted, "best_value": best_value, "best": best, "accept_trace": trace[:, :iterations - 1]}

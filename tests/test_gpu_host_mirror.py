@@ -193,3 +193,16 @@ def test_device_resident_sampler_state_matches_host_loop(mm, oracle_py, shipped)
         assert np.array_equal(dev[k], host[k]), k
     ref = oracle_py.Oracle(pb).metropolis_hastings(x0[0], 17, iters, burn, adaptation_period=ap, thinning=5)
     assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"])
+
+
+def test_chain_groups_on_separate_streams_give_the_single_group_result(mm, oracle_py, shipped):
+    """optimizeChainGroupsOnDevice: 7 chains in 3 ragged groups (one context, stream and host thread each)
+    == one group; chain c draws from mt19937(seed + c) whatever the grouping."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    x0 = oracle_py.Oracle(pb).jitter_draws(pb.base_theta, 9, 7, mode=1)
+    kw = dict(seed=23, iterations=150, burn_in=40, adaptation_period=30, thinning=5)
+    one = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
+    objs = [mm.HostObjective(pb) for _ in range(3)]
+    grp = mm.hostabi.metropolis_hastings_groups(objs, x0, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best"):
+        assert np.array_equal(grp[k], one[k]), k

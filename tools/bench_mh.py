@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--adaptation-period", type=int, default=100)
     ap.add_argument("--arith", default="fma")
     ap.add_argument("--state", choices=["host", "device", "both"], default="both")
+    ap.add_argument("--groups", type=int, nargs="*", default=[], help="also time the device-resident sampler split into G groups")
     args = ap.parse_args()
     mm = mmid_amd_loader.load()
     pb = mm.workloads.build("c1", os.path.join(ROOT, "tests", "golden"))
@@ -37,6 +38,16 @@ def main():
                                          thinning=10, device_state=(state == "device"))
             runs[state] = (time.perf_counter() - t0, r)
         dt, r = runs["device" if "device" in runs else "host"]
+        grouped = {}
+        for G in args.groups:
+            objs = [mm.HostObjective(pb) for _ in range(G)]
+            mm.hostabi.metropolis_hastings_groups(objs, x0[:8 * G], 1, 5, 2)
+            t0 = time.perf_counter()
+            rg = mm.hostabi.metropolis_hastings_groups(objs, x0, 1, args.iterations, args.burn_in,
+                                                       adaptation_period=args.adaptation_period, thinning=10)
+            dtg = time.perf_counter() - t0
+            grouped[G] = {"ms_per_iteration": dtg / (args.iterations - 1) * 1e3, "proposals_per_s": C * (args.iterations - 1) / dtg,
+                          "same_accept_traces": bool(np.array_equal(rg["accept_trace"], r["accept_trace"]))}
         hip = mm.HipObjective(pb)
         hip.eval_batch(x0)
         t1 = time.perf_counter()
@@ -46,7 +57,7 @@ def main():
         print(json.dumps({"chains": C, "iterations": args.iterations, "seconds": dt,
                           "proposals_per_s": C * (args.iterations - 1) / dt, "ms_per_iteration": dt / (args.iterations - 1) * 1e3,
                           "eval_batch_host_pointer_ms": ev * 1e3, "acceptance": float(r["accepted"].mean() / (args.iterations - 1)),
-                          "ms_per_iteration_by_state": {k: v[0] / (args.iterations - 1) * 1e3 for k, v in runs.items()},
+                          "groups": grouped, "ms_per_iteration_by_state": {k: v[0] / (args.iterations - 1) * 1e3 for k, v in runs.items()},
                           "same_accept_traces": (np.array_equal(runs["host"][1]["accept_trace"], runs["device"][1]["accept_trace"])
                                                  if len(runs) == 2 else None)}))
 
