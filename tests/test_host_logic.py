@@ -277,3 +277,19 @@ def test_null_ctx_and_bad_arguments_return_error_codes(mm):
     assert lib.sepaihrd_apply_constraints(None, 0, None, 1, None) == -1
     assert lib.sepaihrd_last_error(None) == b"ctx is NULL"
     lib.sepaihrd_destroy(None)   # no-op
+
+
+def test_missing_hip_library_fails_loudly(mm, tmp_path):
+    """The product path has no CPU fallback: a missing extension is an error, never a silent detour."""
+    missing = str(tmp_path / "libsepaihrd_hip.so")
+    with pytest.raises(FileNotFoundError, match="no CPU fallback"):
+        mm.hipabi.load_library(missing)
+
+
+def test_compute_entry_points_refuse_to_run_without_a_device(mm, shipped, have_gpu):
+    """Without a usable HIP device sepaihrd_create reports SEPAIHRD_E_NO_DEVICE-style failure (no context,
+    message set) instead of evaluating anything on the host."""
+    if have_gpu:
+        pytest.skip("a GPU is present: covered by the -m gpu suite")
+    with pytest.raises(RuntimeError, match="(?i)device|hip"):
+        mm.HipObjective(shipped)
