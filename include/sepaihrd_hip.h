@@ -211,12 +211,16 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
  *   series 3..5  their running sums in time order
  * (ResultAggregator::aggregatePosteriorPredictives, src/model/ResultAggregator.cpp:297-345) and, if
  * sero_quantiles != NULL, of the seroprevalence (sum N - sum_a S_a(t)) / sum N at EVERY output time
- * (MetricsCalculator::calculateSeroprevalenceTrajectory, src/model/MetricsCalculator.cpp:199-226).
+ * (MetricsCalculator::calculateSeroprevalenceTrajectory, src/model/MetricsCalculator.cpp:199-226) and, if
+ * rt_quantiles != NULL, of the effective reproduction number at every output time: the spectral radius of
+ * the next-generation matrix F V^-1 over (E, P, A, I) x age built from S(t), beta(t), kappa(t)
+ * (MetricsCalculator::calculateRtTrajectory :172-197, ReproductionNumberCalculator::calculateRt
+ * src/model/ReproductionNumberCalculator.cpp:55-92,158-171), at most 16 age classes.
  * Quantile rule = exact sort + linear interpolation at q (n_valid - 1)
  * (PostCalibrationAnalyser.cpp:303-340); samples whose integration failed are skipped like the
  * reference's `if (!sim_result.isValid()) continue`.
  *   ppc_quantiles   [6][n_probs][T_pos][n_age]   T_pos = number of output times >= 0
- *   sero_quantiles  [n_probs][n_times] or NULL
+ *   sero_quantiles  [n_probs][n_times] or NULL;  rt_quantiles  [n_probs][n_times] or NULL
  *   status          [S] integrator status per sample, or NULL;  n_valid: count of status 0, or NULL
  * S <= 16384 (one sorted segment lives in LDS); larger ensembles: SEPAIHRD_E_UNSUPPORTED. */
 #define SEPAIHRD_INIT_FROM_THETA 0
@@ -227,7 +231,7 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
 int sepaihrd_set_initial_state_mode(sepaihrd_ctx *ctx, int mode);
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, const double *probs,
                                 int n_probs, double *ppc_quantiles, double *sero_quantiles,
-                                int32_t *status, int32_t *n_valid);
+                                double *rt_quantiles, int32_t *status, int32_t *n_valid);
 
 /* ---- Adaptive-Metropolis chains with their state resident on the device ----
  *

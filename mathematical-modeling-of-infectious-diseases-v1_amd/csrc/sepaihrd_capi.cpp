@@ -530,7 +530,8 @@ int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
 }
 
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, const double* probs, int n_probs,
-                                double* ppc_quantiles, double* sero_quantiles, int32_t* status, int32_t* n_valid) {
+                                double* ppc_quantiles, double* sero_quantiles, double* rt_quantiles, int32_t* status,
+                                int32_t* n_valid) {
     if (!ctx) return SEPAIHRD_E_INVALID_ARG;
     if (S <= 0 || !theta || !probs || n_probs <= 0 || n_probs > 1024 || !ppc_quantiles) {
         ctx->last_error = "ensemble_quantiles: need S > 0, theta, probs (1..1024) and ppc_quantiles";
@@ -559,11 +560,17 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     int rc = ensure_workspace(ctx, chains);
     if (rc != SEPAIHRD_OK) return rc;
 
-    const bool want_sero = sero_quantiles != nullptr;
+    const bool want_sero = sero_quantiles != nullptr, want_rt = rt_quantiles != nullptr;
+    const bool want_traj = want_sero || want_rt;
+    if (want_rt && dp.n > 16) {
+        ctx->last_error = "ensemble_quantiles: Rt trajectories are built for at most 16 age classes";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
     const size_t n_ppc = (size_t)6 * n_probs * Tp * dp.n;
     const size_t n_sero = want_sero ? (size_t)n_probs * dp.T : 0;
-    const size_t n_vals = ((size_t)6 * Tp * dp.n + (want_sero ? dp.T : 0)) * S_pad;
-    const size_t n_traj = want_sero ? (size_t)S * dp.T * NUM_COMP * dp.n : 0;
+    const size_t n_rt = want_rt ? (size_t)n_probs * dp.T : 0;
+    const size_t n_vals = ((size_t)6 * Tp * dp.n + (want_sero ? dp.T : 0) + (want_rt ? dp.T : 0)) * S_pad;
+    const size_t n_traj = want_traj ? (size_t)S * dp.T * NUM_COMP * dp.n : 0;
     double *d_theta = nullptr, *d_ll = nullptr, *d_vals = nullptr, *d_traj = nullptr, *d_probs = nullptr, *d_q = nullptr;
     int32_t* d_nv = nullptr;
     std::vector<void*> tmp;
@@ -575,7 +582,7 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     };
     if (!dalloc((void**)&d_theta, (size_t)S * ctx->P * sizeof(double)) || !dalloc((void**)&d_ll, (size_t)S * sizeof(double)) ||
         !dalloc((void**)&d_vals, n_vals * sizeof(double)) || !dalloc((void**)&d_traj, n_traj * sizeof(double)) ||
-        !dalloc((void**)&d_probs, (size_t)n_probs * sizeof(double)) || !dalloc((void**)&d_q, (n_ppc + n_sero) * sizeof(double)) ||
+        !dalloc((void**)&d_probs, (size_t)n_probs * sizeof(double)) || !dalloc((void**)&d_q, (n_ppc + n_sero + n_rt) * sizeof(double)) ||
         !dalloc((void**)&d_nv, sizeof(int32_t))) {
         cleanup();
         ctx->last_error = "ensemble_quantiles: device allocation failed";
@@ -585,7 +592,7 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
             { cleanup(); return SEPAIHRD_E_HIP; });
     HIP_TRY(hipMemcpy(d_probs, probs, (size_t)n_probs * sizeof(double), hipMemcpyHostToDevice), ctx,
             { cleanup(); return SEPAIHRD_E_HIP; });
-    EvalOutputs out{d_ll, nullptr, nullptr, nullptr, nullptr, want_sero ? d_traj : nullptr,
+    EvalOutputs out{d_ll, nullptr, nullptr, nullptr, nullptr, want_traj ? d_traj : nullptr,
                     ctx->ws_cum, ctx->ws_rows, ctx->ws_status, nullptr, 1};
     rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(dp, ctx->solver, d_theta, S, out, nullptr)
                                           : launch_eval_strict(dp, ctx->solver, d_theta, S, out, nullptr);
@@ -600,9 +607,13 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     a.S = S; a.S_pad = S_pad; a.lpc = dp.lpc; a.n = dp.n; a.T = dp.T; a.Tp = Tp; a.runup_offset = dp.runup_offset;
     a.n_probs = n_probs;
     a.cum_stride = chains * dp.lpc;
-    a.cum = ctx->ws_cum; a.wstatus = ctx->ws_status; a.traj = want_sero ? d_traj : nullptr;
+    a.cum = ctx->ws_cum; a.wstatus = ctx->ws_status; a.traj = want_traj ? d_traj : nullptr;
     a.total_pop = total_pop;
     a.vals = d_vals; a.probs = d_probs; a.q_out = d_q; a.sero_out = want_sero ? d_q + n_ppc : nullptr; a.n_valid = d_nv;
+    a.rt_out = want_rt ? d_q + n_ppc + n_sero : nullptr;
+    a.rt_segment0 = 6 * Tp * dp.n + (want_sero ? dp.T : 0);
+    a.pb = &ctx->dp;
+    a.theta = d_theta;
     rc = launch_ensemble_summaries(a, nullptr);
     if (rc != 0) {
         cleanup();
@@ -613,6 +624,9 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     HIP_TRY(hipMemcpy(ppc_quantiles, d_q, n_ppc * sizeof(double), hipMemcpyDeviceToHost), ctx, { cleanup(); return SEPAIHRD_E_HIP; });
     if (want_sero)
         HIP_TRY(hipMemcpy(sero_quantiles, d_q + n_ppc, n_sero * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                { cleanup(); return SEPAIHRD_E_HIP; });
+    if (want_rt)
+        HIP_TRY(hipMemcpy(rt_quantiles, d_q + n_ppc + n_sero, n_rt * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 { cleanup(); return SEPAIHRD_E_HIP; });
     if (status)
         HIP_TRY(hipMemcpy(status, ctx->ws_status, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,

@@ -98,11 +98,16 @@ struct EnsembleArgs {
     const int32_t* wstatus;   // [S] integrator status
     const double* traj;       // [S][T][11][n] or null (seroprevalence needs S(t))
     double total_pop;
-    double* vals;             // [(6 Tp n) + T][S_pad] series values, one sortable segment per row
+    double* vals;             // [(6 Tp n) + T (sero) + T (Rt)][S_pad] series values, one sortable segment per row
     const double* probs;      // [n_probs] device
     double* q_out;            // [6][n_probs][Tp][n] device
     double* sero_out;         // [n_probs][T] device or null
     int32_t* n_valid;         // [1] device
+    // effective reproduction number (needs traj): one more block of T segments starting at rt_segment0
+    double* rt_out;           // [n_probs][T] device or null
+    int rt_segment0;
+    const DevProblem* pb;     // host pointer to the ctx's problem (kernel argument by value)
+    const double* theta;      // [S][P] device, the samples
 };
 int launch_ensemble_summaries(const EnsembleArgs& a, void* stream);
 

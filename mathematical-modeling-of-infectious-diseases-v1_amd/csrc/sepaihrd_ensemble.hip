@@ -9,6 +9,7 @@
 //              output times t >= 0 (previous point = last run-up point or the initial state),
 //              cumulative = running sum of the daily values in time order; X in {CumH, CumICU, D}
 //   sero       src/model/MetricsCalculator.cpp:199-226  (sum N - sum_a S_a(t)) / sum N, every time
+//   Rt         src/model/ReproductionNumberCalculator.cpp:55-171  spectral radius of F V^-1 (below)
 //   quantile   src/model/PostCalibrationAnalyser.cpp:303-340  exact sort, pos = q (n - 1),
 //              v[floor pos] (1 - frac) + v[floor pos + 1] frac
 // The reference feeds the six incidence series through Boost.Accumulators' P^2 estimator
@@ -100,6 +101,97 @@ __global__ __launch_bounds__(WAVE) void ensemble_series_kernel(const EnsembleArg
     }
 }
 
+// SEPAIHRDParameterManager.cpp:302-313 / :326-343 (same code as the evaluation kernel's)
+__device__ __forceinline__ double ens_reflect_bound(double value, double minb, double maxb) {
+    if (minb >= maxb) return minb;
+    const double width = maxb - minb;
+    double y = fmod(value - minb, 2.0 * width);
+    if (y < 0) y += 2.0 * width;
+    if (y <= width) return minb + y;
+    return maxb - (y - width);
+}
+__device__ __forceinline__ double ens_constrain(const DevProblem& pb, const double* th, int p) {
+    const double v = th[p];
+    double lo = pb.lower[p], hi = pb.upper[p];
+    if (pb.has_bounds[p]) {
+        if (lo > hi) { const double t = lo; lo = hi; hi = t; }
+        if (pb.constraint_mode == 0) {
+            const double m = (v < lo) ? lo : v;
+            return (hi < m) ? hi : m;
+        }
+        return ens_reflect_bound(v, lo, hi);
+    }
+    if (pb.constraint_mode == 0) return (0.0 < v) ? v : 0.0;
+    return fabs(v);
+}
+__device__ __forceinline__ double ens_scalar(const DevProblem& pb, const double* th, int slot) {
+    const int src = pb.src_scalar[slot];
+    return src >= 0 ? ens_constrain(pb, th, src) : pb.base_scalar[slot];
+}
+__device__ __forceinline__ double ens_vec(const DevProblem& pb, const double* th, int field, int age) {
+    const int src = pb.src_vec[field * pb.lpc + age];
+    return src >= 0 ? ens_constrain(pb, th, src) : pb.base_vec[field * pb.lpc + age];
+}
+
+// Effective reproduction number of sample s at output time k
+// (ReproductionNumberCalculator::calculateRt, src/model/ReproductionNumberCalculator.cpp:55-92,95-171):
+// spectral radius of the next-generation matrix K = F V^-1 over the states (E, P, A, I) x age.
+// F has entries only in its E rows: F(E_i, {P_j, A_j}) = T_ij, F(E_i, I_j) = theta T_ij with
+// T_ij = max(0, beta(t) kappa(t) M_ij a_i h_infec_j S_i / N_j); V is block lower-triangular
+// (sigma, gamma_p, p gamma_p, (1-p) gamma_p, gamma_A, gamma_I + h), so V^-1 restricted to the E columns is
+// closed form and the non-zero spectrum of K is that of the n x n block
+//   K_EE(i, j) = T_ij (1/gamma_p + p_j/gamma_A + theta (1 - p_j)/(gamma_I + h_j)).
+// K_EE is non-negative: its spectral radius is its Perron root, taken by power iteration in the
+// max-norm (the reference calls Eigen::EigenSolver on the full 4n x 4n matrix: same number to rounding).
+constexpr int RT_MAX_AGE = 16;
+__global__ __launch_bounds__(WAVE) void ensemble_rt_kernel(const EnsembleArgs a, const DevProblem pb, const double* theta) {
+    const size_t idx = (size_t)blockIdx.x * WAVE + threadIdx.x;
+    const int s = (int)(idx % a.S_pad);  // sample fastest: the segment row is written coalesced
+    const int k = (int)(idx / a.S_pad);
+    if (k >= a.T) return;
+    double* out = a.vals + ((size_t)a.rt_segment0 + k) * a.S_pad;
+    if (!(s < a.S && a.wstatus[s] == 0)) { out[s] = INFINITY; return; }
+    const double* th = theta + (size_t)s * pb.P;
+    const int n = a.n;
+    const double t = pb.times[k];
+    int seg = 0;
+    for (int j = 0; j < pb.nm; ++j) seg += (pb.mends[j] < t) ? 1 : 0;
+    const double beta = (pb.nb > 0) ? ens_scalar(pb, th, SS_SCHEDULE0 + pb.seg_ib[seg]) : ens_scalar(pb, th, SS_BETA);
+    const double kappa = ens_scalar(pb, th, SS_SCHEDULE0 + pb.nb + pb.seg_ik[seg]);
+    const double theta_i = ens_scalar(pb, th, SS_THETA);
+    const double gamma_p = ens_scalar(pb, th, SS_GAMMA_P), gamma_A = ens_scalar(pb, th, SS_GAMMA_A),
+                 gamma_I = ens_scalar(pb, th, SS_GAMMA_I);
+    const double* row = a.traj + ((size_t)s * a.T + k) * (NUM_COMP * n);  // S block first
+    double ci[RT_MAX_AGE], gj[RT_MAX_AGE], v[RT_MAX_AGE], w[RT_MAX_AGE];
+    for (int i = 0; i < n; ++i) {
+        ci[i] = beta * kappa * ens_vec(pb, th, VF_A, i) * row[i];  // beta kappa a_i S_i
+        const double Nj = pb.N[i];
+        const double pj = ens_vec(pb, th, VF_P, i), hj = ens_vec(pb, th, VF_H, i);
+        const double dwell = 1.0 / gamma_p + pj / gamma_A + theta_i * (1.0 - pj) / (gamma_I + hj);
+        gj[i] = (Nj < 1e-9) ? 0.0 : ens_vec(pb, th, VF_H_INFEC, i) / Nj * dwell;
+        v[i] = 1.0;
+    }
+    double lambda = 0.0;
+    for (int it = 0; it < 2000; ++it) {
+        double m = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double tij = ci[i] * pb.Mrow[i * pb.lpc + j] * gj[j];
+                acc += ((0.0 < tij) ? tij : 0.0) * v[j];
+            }
+            w[i] = acc;
+            m = (acc > m) ? acc : m;
+        }
+        if (!(m > 0.0)) { lambda = 0.0; break; }
+        for (int i = 0; i < n; ++i) v[i] = w[i] / m;
+        const bool done = fabs(m - lambda) <= 1e-15 * m;
+        lambda = m;
+        if (done) break;
+    }
+    out[s] = lambda;
+}
+
 // Pass 2: one workgroup per segment; bitonic sort in LDS, then the interpolated quantiles.
 __global__ void ensemble_quantile_kernel(const EnsembleArgs a, const int n_series_segments) {
     extern __shared__ double seg[];
@@ -135,6 +227,8 @@ __global__ void ensemble_quantile_kernel(const EnsembleArgs a, const int n_serie
             const int t = (int)((sid / a.n) % a.Tp);
             const int ser = (int)(sid / ((size_t)a.n * a.Tp));
             a.q_out[(((size_t)ser * a.n_probs + p) * a.Tp + t) * a.n + age] = r;
+        } else if (a.rt_out != nullptr && (int)sid >= a.rt_segment0) {
+            a.rt_out[(size_t)p * a.T + (sid - (size_t)a.rt_segment0)] = r;
         } else {
             const size_t k = sid - (size_t)n_series_segments;
             a.sero_out[(size_t)p * a.T + k] = r;
@@ -153,7 +247,13 @@ int launch_ensemble_summaries(const EnsembleArgs& a, void* stream) {
     hipLaunchKernelGGL(ensemble_series_kernel, dim3((unsigned)((cols + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a);
     const int n_series_segments = 6 * a.Tp * a.n;
     const bool sero = a.traj != nullptr && a.sero_out != nullptr;
-    const int segments = n_series_segments + (sero ? a.T : 0);
+    const bool rt = a.traj != nullptr && a.rt_out != nullptr;
+    if (rt && (a.n > RT_MAX_AGE || a.rt_segment0 != n_series_segments + (sero ? a.T : 0))) return -4;
+    if (rt) {
+        const size_t cells = (size_t)a.S_pad * a.T;
+        hipLaunchKernelGGL(ensemble_rt_kernel, dim3((unsigned)((cells + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a, *a.pb, a.theta);
+    }
+    const int segments = n_series_segments + (sero ? a.T : 0) + (rt ? a.T : 0);
     const int threads = a.S_pad / 2 < 1024 ? a.S_pad / 2 : 1024;
     const size_t lds = (size_t)a.S_pad * sizeof(double);
     if (lds > 48 * 1024 &&

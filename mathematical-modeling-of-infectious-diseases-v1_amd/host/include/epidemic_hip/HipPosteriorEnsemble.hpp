@@ -11,7 +11,8 @@
 // launch; the per-time quantiles come from an exact sort on the device.  Differences from the
 // reference, by design: the incidence quantiles use the exact-sort rule of
 // PostCalibrationAnalyser.cpp:316-326 instead of Boost.Accumulators' order-dependent P^2 estimate;
-// Rt trajectories (dense eigenvalue problem per sample and time) are not on this path.
+// the Rt values are the Perron root of the n x n block that carries the next-generation matrix's spectrum
+// (power iteration) instead of Eigen::EigenSolver on the 4n x 4n matrix: same number to rounding.
 #pragma once
 #include <map>
 #include <memory>
@@ -53,6 +54,10 @@ public:
     // samples burn_in, burn_in + thinning, ... (PostCalibrationAnalyser.cpp:209); one entry per output time
     std::map<double, AggregatedStats> aggregateSeroprevalence(const std::vector<Eigen::VectorXd>& param_samples,
                                                               int burn_in, int thinning);
+    // effective reproduction number per output time over the same samples ("Rt_aggregated_with_uncertainty",
+    // PostCalibrationAnalyser.cpp:233-236,342; MetricsCalculator::calculateRtTrajectory :172-197)
+    std::map<double, AggregatedStats> aggregateRt(const std::vector<Eigen::VectorXd>& param_samples, int burn_in,
+                                                  int thinning);
 
 private:
     void run(const std::vector<double>& thetas, int S, bool want_sero);
@@ -62,7 +67,7 @@ private:
     SimulationCache cache_;
     std::unique_ptr<HipSEPAIHRDObjectiveFunction> objective_;
     int n_ = 0, t_pos_ = 0;
-    std::vector<double> ppc_, sero_;  // [6][5][T_pos][n], [5][T]
+    std::vector<double> ppc_, sero_, rt_;  // [6][5][T_pos][n], [5][T], [5][T]
     int n_valid_ = 0;
 };
 

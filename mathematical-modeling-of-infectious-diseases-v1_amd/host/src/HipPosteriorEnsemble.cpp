@@ -51,8 +51,9 @@ void HipPosteriorEnsemble::run(const std::vector<double>& thetas, int S, bool wa
     ppc_.assign(static_cast<size_t>(6) * 5 * t_pos_ * n_, 0.0);
     sero_.assign(want_sero ? static_cast<size_t>(5) * time_points_.size() : 0, 0.0);
     int32_t nv = 0;
+    rt_.assign(want_sero ? static_cast<size_t>(5) * time_points_.size() : 0, 0.0);
     const int rc = sepaihrd_ensemble_quantiles(ctx, thetas.data(), S, kProbs, 5, ppc_.data(),
-                                               want_sero ? sero_.data() : nullptr, nullptr, &nv);
+                                               want_sero ? sero_.data() : nullptr, want_sero ? rt_.data() : nullptr, nullptr, &nv);
     if (rc != SEPAIHRD_OK)
         throw ModelException("HipPosteriorEnsemble", std::string("sepaihrd_ensemble_quantiles: ") + sepaihrd_last_error(ctx));
     n_valid_ = nv;
@@ -114,6 +115,22 @@ std::map<double, AggregatedStats> HipPosteriorEnsemble::aggregateSeroprevalence(
     for (size_t k = 0; k < T; ++k) {
         AggregatedStats st;
         for (int p = 0; p < 5; ++p) st[keys[p]] = sero_[static_cast<size_t>(p) * T + k];
+        out[time_points_[k]] = st;
+    }
+    return out;
+}
+
+std::map<double, AggregatedStats> HipPosteriorEnsemble::aggregateRt(const std::vector<Eigen::VectorXd>& param_samples,
+                                                                    int burn_in, int thinning) {
+    // same ensemble, same launch as the seroprevalence: PostCalibrationAnalyser.cpp:233-236,342
+    const std::map<double, AggregatedStats> sero = aggregateSeroprevalence(param_samples, burn_in, thinning);
+    std::map<double, AggregatedStats> out;
+    if (sero.empty()) return out;
+    const size_t T = time_points_.size();
+    const char* keys[5] = {"q025", "q05", "median", "q95", "q975"};
+    for (size_t k = 0; k < T; ++k) {
+        AggregatedStats st;
+        for (int p = 0; p < 5; ++p) st[keys[p]] = rt_[static_cast<size_t>(p) * T + k];
         out[time_points_[k]] = st;
     }
     return out;

@@ -102,11 +102,11 @@ void host_objective_destroy(void* hv) { delete static_cast<HostHandle*>(hv); }
 
 // HipPosteriorEnsemble over the handle's parameter manager / data.  samples: n_samples x P.
 // ppc: [6 series][5: lower_95, lower_90, median, upper_90, upper_95][T_pos][n]; selected: capacity
-// max(n_samples, num_for_ppc) indices actually simulated; sero (nullable): [5: q025,q05,median,q95,q975][T]
+// max(n_samples, num_for_ppc) indices actually simulated; sero / rt (nullable): [5: q025,q05,median,q95,q975][T]
 // over samples burn_in, burn_in + thinning, ...
 int host_ensemble(void* hv, const sepaihrd_problem* pb, int device, const double* samples, int n_samples,
                   int num_for_ppc, uint32_t seed, double* ppc, int32_t* selected, int32_t* n_selected,
-                  int32_t* samples_used, int burn_in, int thinning, double* sero) {
+                  int32_t* samples_used, int burn_in, int thinning, double* sero, double* rt) {
     auto* h = static_cast<HostHandle*>(hv);
     try {
         const int n = pb->n_age;
@@ -146,6 +146,18 @@ int host_ensemble(void* hv, const sepaihrd_problem* pb, int device, const double
                 const auto it = agg.find(t);
                 for (int q = 0; q < 5; ++q)
                     sero[static_cast<size_t>(q) * times.size() + k] =
+                        it == agg.end() ? std::numeric_limits<double>::quiet_NaN() : it->second.at(keys[q]);
+                ++k;
+            }
+        }
+        if (rt) {
+            const auto agg = ens.aggregateRt(ps, burn_in, thinning);
+            const char* keys[5] = {"q025", "q05", "median", "q95", "q975"};
+            size_t k = 0;
+            for (double t : times) {
+                const auto it = agg.find(t);
+                for (int q = 0; q < 5; ++q)
+                    rt[static_cast<size_t>(q) * times.size() + k] =
                         it == agg.end() ? std::numeric_limits<double>::quiet_NaN() : it->second.at(keys[q]);
                 ++k;
             }

@@ -45,7 +45,7 @@ def load_library() -> C.CDLL:
                                    C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
-                                  vp, vp, vp, vp, C.c_int, C.c_int, vp]
+                                  vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     _lib = lib
     return lib
 
@@ -128,7 +128,7 @@ class HostObjective:
         return out
 
     def posterior_ensemble(self, samples, num_for_ppc: int, seed: int, burn_in: int = 0, thinning: int = 1,
-                           want_sero: bool = True, device: int = -1) -> dict:
+                           want_sero: bool = True, want_rt: bool = False, device: int = -1) -> dict:
         """HipPosteriorEnsemble::aggregatePosteriorPredictives (+ aggregateSeroprevalence) over this handle's
         parameter manager and data.  ppc: [6][5: lower_95, lower_90, median, upper_90, upper_95][T_pos][n]."""
         ps = np.ascontiguousarray(np.atleast_2d(samples), dtype=np.float64)
@@ -140,12 +140,13 @@ class HostObjective:
         sel = np.empty(max(ps.shape[0], num_for_ppc, 1), dtype=np.int32)
         nsel, used = C.c_int32(0), C.c_int32(0)
         sero = np.empty((5, T)) if want_sero else None
+        rt = np.empty((5, T)) if want_rt else None
         rc = self.lib.host_ensemble(self.h, C.byref(st), device, ps.ctypes.data, ps.shape[0], num_for_ppc, seed,
                                     ppc.ctypes.data, sel.ctypes.data, C.byref(nsel), C.byref(used), burn_in, thinning,
-                                    sero.ctypes.data if want_sero else None)
+                                    sero.ctypes.data if want_sero else None, rt.ctypes.data if want_rt else None)
         if rc != 0:
             raise RuntimeError("host_ensemble: " + self.lib.host_last_error().decode())
-        return {"ppc": ppc, "selected": sel[:nsel.value].copy(), "samples_used": used.value, "sero": sero}
+        return {"ppc": ppc, "selected": sel[:nsel.value].copy(), "samples_used": used.value, "sero": sero, "rt": rt}
 
     def calculate(self, theta) -> float:
         th = np.ascontiguousarray(theta, dtype=np.float64)

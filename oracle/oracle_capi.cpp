@@ -335,6 +335,36 @@ int oracle_sir_simulate(int n, const double* N, const double* C, const double* g
     } catch (const std::exception&) { return 2; }
 }
 
+int oracle_model_parameters(void* hv, const double* theta, double* out) {
+    auto* h = static_cast<Handle*>(hv);
+    const int P = static_cast<int>(h->pb.pm.names.size());
+    oracle::Model model(h->pb.base);
+    try {
+        h->pb.pm.updateModelParameters(std::vector<double>(theta, theta + P), model);
+    } catch (...) { return -1; }
+    const oracle::Params& m = model.P;
+    std::vector<double> v = {m.beta, m.theta, m.sigma, m.gamma_p, m.gamma_A, m.gamma_I, m.gamma_H, m.gamma_ICU};
+    for (const std::vector<double>* f : {&m.a, &m.h_infec, &m.p, &m.h, &m.icu, &m.d_H, &m.d_ICU, &m.d_community})
+        v.insert(v.end(), f->begin(), f->end());
+    v.insert(v.end(), m.beta_values.begin(), m.beta_values.end());
+    v.insert(v.end(), m.kappa_values.begin(), m.kappa_values.end());
+    std::copy(v.begin(), v.end(), out);
+    return static_cast<int>(v.size());
+}
+
+int oracle_simulate_samples(void* hv, const double* theta, int S, double* traj, int32_t* status, int nthreads) {
+    auto* h = static_cast<Handle*>(hv);
+    const int P = static_cast<int>(h->pb.pm.names.size());
+    const size_t per = h->pb.time_points.size() * static_cast<size_t>(oracle::NUM_COMPARTMENTS) * h->pb.base.n;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic)
+    for (int s = 0; s < S; ++s) {
+        std::vector<double> tr;
+        status[s] = oracle::simulate_sample(h->pb, std::vector<double>(theta + static_cast<size_t>(s) * P, theta + static_cast<size_t>(s + 1) * P), tr);
+        if (status[s] == 0) std::copy(tr.begin(), tr.end(), traj + static_cast<size_t>(s) * per);
+    }
+    return 0;
+}
+
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t* out) {
     const std::vector<int> sel = oracle::select_ppc_samples(static_cast<size_t>(n_samples), num_for_ppc, seed);
     std::copy(sel.begin(), sel.end(), out);

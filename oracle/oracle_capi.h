@@ -74,6 +74,13 @@ void oracle_sir_rhs(int n, const double *N, const double *C, const double *gamma
 int oracle_sir_simulate(int n, const double *N, const double *C, const double *gamma, double q, double scale_C,
                         const double *init, const double *times, int n_times, double abs_err, double rel_err,
                         double *traj, int32_t *n_accept, int32_t *n_reject);
+/* model fields after updateModelParameters(theta): [beta, theta, sigma, gamma_p, gamma_A, gamma_I, gamma_H, gamma_ICU,
+ * a[n], h_infec[n], p[n], h[n], icu[n], d_H[n], d_ICU[n], d_community[n], beta_values[n_beta], kappa_values[n_kappa]];
+ * returns the number of doubles written, or -1 when the update throws */
+int oracle_model_parameters(void *h, const double *theta, double *out);
+/* trajectories of S samples from the problem's initial state AS GIVEN (SimulationRunner::runSimulation):
+ * traj [S][T][11 n], status [S] */
+int oracle_simulate_samples(void *h, const double *theta, int S, double *traj, int32_t *status, int nthreads);
 /* returns the number of indices written (ResultAggregator.cpp:246-266) */
 int oracle_ppc_select(int n_samples, int num_for_ppc, uint32_t seed, int32_t *out);
 int oracle_num_threads(void);

@@ -78,6 +78,8 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_sir_rhs.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp]
     lib.oracle_sir_simulate.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, C.c_int, C.c_double,
                                         C.c_double, vp, vp, vp]
+    lib.oracle_model_parameters.argtypes = [vp, vp, vp]
+    lib.oracle_simulate_samples.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
     lib.oracle_ppc_select.argtypes = [C.c_int, C.c_int, C.c_uint32, vp]
     lib.oracle_ensemble.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int]
     if path is None:
@@ -196,6 +198,33 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("SimulationException")
         return v.value, g
+
+    def model_parameters(self, theta) -> dict:
+        """Model fields after updateModelParameters(theta) (SEPAIHRDParameterManager.cpp:164-287)."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        n, nb, nk = self.n, len(self.pb.beta_values), len(self.pb.kappa_values)
+        buf = np.empty(8 + 8 * n + nb + nk)
+        k = self.lib.oracle_model_parameters(self.h, th.ctypes.data, buf.ctypes.data)
+        if k < 0:
+            raise ValueError("updateModelParameters throws for this theta")
+        out = dict(zip(("beta", "theta", "sigma", "gamma_p", "gamma_A", "gamma_I", "gamma_H", "gamma_ICU"), buf[:8]))
+        o = 8
+        for name in ("a", "h_infec", "p", "h", "icu", "d_H", "d_ICU", "d_community"):
+            out[name] = buf[o:o + n].copy(); o += n
+        out["beta_values"] = buf[o:o + nb].copy(); o += nb
+        out["kappa_values"] = buf[o:o + nk].copy()
+        return out
+
+    def simulate_samples(self, theta, nthreads: int = 0) -> dict:
+        """Trajectories from the problem's initial state as given (fixed-state ensemble runs)."""
+        th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        S = th.shape[0]
+        traj = np.zeros((S, self.T, 11 * self.n))
+        status = np.empty(S, dtype=np.int32)
+        if nthreads <= 0:
+            nthreads = self.lib.oracle_num_threads()
+        self.lib.oracle_simulate_samples(self.h, th.ctypes.data, S, traj.ctypes.data, status.ctypes.data, nthreads)
+        return {"traj": traj, "status": status}
 
     def condition_covariance(self, cov) -> np.ndarray:
         c = np.ascontiguousarray(cov, dtype=np.float64)

@@ -123,7 +123,7 @@ def test_host_posterior_ensemble_mirror(mm, oracle_py, shipped):
     n_samples, num_for_ppc, seed = 120, 40, 2024
     samples = _draws(oracle_py, pb, n_samples, seed0=77)
     host = mm.HostObjective(pb)
-    got = host.posterior_ensemble(samples, num_for_ppc, seed, burn_in=20, thinning=3)
+    got = host.posterior_ensemble(samples, num_for_ppc, seed, burn_in=20, thinning=3, want_rt=True)
     sel = oracle_py.ppc_select(n_samples, num_for_ppc, seed)
     assert np.array_equal(got["selected"], sel) and len(sel) == num_for_ppc
     orc = oracle_py.Oracle(pb)
@@ -132,6 +132,7 @@ def test_host_posterior_ensemble_mirror(mm, oracle_py, shipped):
     np.testing.assert_allclose(got["ppc"], ref["ppc"], rtol=1e-9, atol=1e-9)
     ref_sero = orc.ensemble_quantiles(samples[20::3], PROBS)["sero"]
     np.testing.assert_allclose(got["sero"], ref_sero, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got["rt"], _rt_reference(oracle_py, pb, samples[20::3])[1], rtol=1e-9)
     # num_for_ppc >= size: every sample once, in order (ResultAggregator.cpp:263-266)
     allsel = host.posterior_ensemble(samples[:10], 50, seed, want_sero=False)["selected"]
     assert np.array_equal(allsel, np.arange(10))
@@ -144,3 +145,59 @@ def test_ppc_sample_selection_rule(oracle_py):
     assert not np.array_equal(sel, oracle_py.ppc_select(1000, 25, 12346))
     assert np.array_equal(oracle_py.ppc_select(7, 0, 1), np.arange(7))
     assert np.array_equal(oracle_py.ppc_select(7, 7, 1), np.arange(7))
+
+
+def _rt_reference(oracle_py, pb, theta):
+    import rt_numpy
+    orc = oracle_py.Oracle(pb)
+    sim = orc.simulate_samples(theta)
+    assert np.all(sim["status"] == 0)
+    rts = np.array([rt_numpy.rt_trajectory(sim["traj"][s], orc.model_parameters(theta[s]), pb) for s in range(len(theta))])
+    q = np.array([[rt_numpy.sorted_quantile(rts[:, k], p) for k in range(rts.shape[1])] for p in PROBS])
+    return rts, q
+
+
+def test_rt_spectrum_lives_in_the_exposed_block(oracle_py, shipped):
+    """The next-generation matrix F V^-1 (4n x 4n, ReproductionNumberCalculator.cpp:55-171) has non-zero
+    rows only for E: its spectral radius is the Perron root of the n x n block
+    T_ij (1/gamma_p + p_j/gamma_A + theta (1 - p_j)/(gamma_I + h_j)) the device path iterates on."""
+    import rt_numpy
+    pb = shipped
+    orc = oracle_py.Oracle(pb)
+    theta = _draws(oracle_py, pb, 3)
+    sim = orc.simulate_samples(theta)
+    n = pb.n
+    N, M = np.asarray(pb.N), np.asarray(pb.M).reshape(n, n)
+    for s in range(3):
+        mp = orc.model_parameters(theta[s])
+        for k in (0, 25, 140, pb.n_times - 1):
+            t, S = pb.times[k], sim["traj"][s, k, :n]
+            full = rt_numpy.rt_value(S, t, mp, pb)
+            kappa = mp["kappa_values"][0] if t < 0 else rt_numpy._piecewise(pb.kappa_end_times, mp["kappa_values"], t)
+            beta = rt_numpy._piecewise(pb.beta_end_times, mp["beta_values"], t) if len(mp["beta_values"]) else mp["beta"]
+            T = np.maximum(0.0, beta * kappa * M * mp["a"][:, None] * mp["h_infec"][None, :] * S[:, None] / N[None, :])
+            dwell = 1.0 / mp["gamma_p"] + mp["p"] / mp["gamma_A"] + mp["theta"] * (1.0 - mp["p"]) / (mp["gamma_I"] + mp["h"])
+            block = np.max(np.abs(np.linalg.eigvals(T * dwell[None, :])))
+            assert abs(block - full) <= 1e-12 * full, (s, k, block, full)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [0, 1])
+def test_hip_rt_trajectory_quantiles(mm, oracle_py, shipped, solver):
+    """Rt quantiles of the device ensemble against the numpy restatement of ReproductionNumberCalculator
+    (F, V, inverse, eigenvalues through LAPACK) on the oracle's trajectories."""
+    pb = shipped.with_(solver=solver, arith=mm.ARITH_STRICT)
+    S = 25
+    theta = _draws(oracle_py, pb, S)
+    rts, q = _rt_reference(oracle_py, pb, theta)
+    assert 0.05 < rts.min() < 1.0 < rts.max() < 10.0  # an epidemic that grows and is brought under control
+    hip = mm.HipObjective(pb)
+    hip.set_initial_state_mode(1)
+    got = hip.ensemble_quantiles(theta, PROBS, want_sero=True, want_rt=True)
+    assert got["n_valid"] == S
+    np.testing.assert_allclose(got["rt"], q, rtol=1e-9)
+    # the other summaries are unchanged by asking for Rt
+    plain = hip.ensemble_quantiles(theta, PROBS, want_sero=True)
+    assert np.array_equal(plain["ppc"], got["ppc"]) and np.array_equal(plain["sero"], got["sero"])
+    only_rt = hip.ensemble_quantiles(theta, PROBS, want_sero=False, want_rt=True)
+    assert np.array_equal(only_rt["rt"], got["rt"])

@@ -30,13 +30,13 @@ def main():
     hip.set_initial_state_mode(1)
     for S in args.samples:
         theta = mm.draws.jitter_draws(pb, 1, S)
-        for sero in (False, True):
-            hip.ensemble_quantiles(theta[:64], probs, want_sero=sero)
+        for sero, rt in ((False, False), (True, False), (True, True)):
+            hip.ensemble_quantiles(theta[:64], probs, want_sero=sero, want_rt=rt)
             t0 = time.perf_counter()
             for _ in range(args.reps):
-                r = hip.ensemble_quantiles(theta, probs, want_sero=sero)
+                r = hip.ensemble_quantiles(theta, probs, want_sero=sero, want_rt=rt)
             dt = (time.perf_counter() - t0) / args.reps
-            print(json.dumps({"samples": S, "seroprevalence": sero, "ms": dt * 1e3, "samples_per_s": S / dt,
+            print(json.dumps({"samples": S, "seroprevalence": sero, "rt": rt, "ms": dt * 1e3, "samples_per_s": S / dt,
                               "n_valid": r["n_valid"], "segments": 6 * r["ppc"].shape[2] * pb.n + (pb.n_times if sero else 0)}))
 
 
