@@ -289,15 +289,13 @@ __device__ __forceinline__ double log_pos(double x) {
 }
 
 // |e| / s of the error norm.  strict: the IEEE division of the CPU build.  fma: Newton-refined
-// reciprocal plus one residual correction (<= 1 ulp, 9 instructions instead of 15); s > 0 is a
-// tolerance scale, far from the overflow / underflow cases the IEEE sequence guards against.
+// reciprocal (4 instructions instead of 15); s > 0 is a tolerance scale, far from the overflow /
+// underflow cases the IEEE sequence guards against.
 __device__ __forceinline__ double quotient(double e, double s) {
 #if SEPAIHRD_ARITH_FMA
-    double r = __builtin_amdgcn_rcp(s);
-    r = fma(fma(-s, r, 1.0), r, r);
-    r = fma(fma(-s, r, 1.0), r, r);
-    const double q = e * r;
-    return fma(fma(-s, q, e), r, q);
+    double r = __builtin_amdgcn_rcp(s);   // ~2^-26 relative
+    r = fma(fma(-s, r, 1.0), r, r);       // one Newton step: ~2^-52
+    return e * r;                         // a couple of ulp: the value only drives the step-size rule
 #else
     return e / s;
 #endif
@@ -328,7 +326,17 @@ __device__ __forceinline__ double exp_ctl(double p) {
 }
 // x^c for the controller's err^(-1/3), err^(-1/5): exp(c log x), a few ulp -- the reference calls
 // std::pow (libm, not bit-pinned); the result only scales the next trial step.
-__device__ __forceinline__ double pow_ctl(double x, double c) { return exp_ctl(c * log_pos(x)); }
+__device__ __forceinline__ double pow_ctl(double x, double c) {
+#if SEPAIHRD_ARITH_FMA
+    // tolerance mode: the factor only scales the next TRIAL step, whose local error the controller checks
+    // again; the hardware's single-precision log2 / exp2 (~1e-7 relative) are exact enough and cost five
+    // instructions instead of fifty-seven.  err = +inf gives 0 (floored at 1/5 by the caller), like pow.
+    const float l2 = __builtin_amdgcn_logf((float)x);
+    return (double)__builtin_amdgcn_exp2f((float)c * l2);
+#else
+    return exp_ctl(c * log_pos(x));
+#endif
+}
 
 // ----------------------------------------------------------------------------------
 // the evaluation kernel: block = one wavefront = 64/LPC chains
