@@ -403,7 +403,7 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
     const size_t cpw = (size_t)(WAVE / ctx->dp.lpc);
     const size_t waves = ((size_t)B + cpw - 1) / cpw;
     // batches that fill the chip use the inline-likelihood kernel and need no workspace / chunking
-    const bool split = waves <= (size_t)SPLIT_LL_MAX_BLOCKS;
+    const bool split = split_likelihood(ctx->solver, ctx->arith == SEPAIHRD_ARITH_FMA, waves);
     const size_t chunk = split ? chunk_chains(ctx, (size_t)B) : (size_t)B;
     if (split) {
         const int rc = ensure_workspace(ctx, chunk);

@@ -124,7 +124,14 @@ inline int lanes_per_chain(int n) {
 //   [.., + cpw*P)                 constrained theta of the wave's chains (prologue only)
 constexpr int MAX_TIMES = 12288;  // output grid staged in LDS (96 KiB at the cap)
 constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;  // LDS-DMA landing zone of the inline-likelihood build
-constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is used
+constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is always used
+// Which form of the likelihood a launch of `waves` wavefronts uses.  Up to one wave per SIMD the chip is not
+// full and the separate pass always wins.  Beyond that it still wins for Dopri5 in fma arithmetic, whose
+// integrator without the inline logs fits 256 registers (two waves per SIMD, no spills: 14.9 M vs 13.9 M evals/s
+// at 32 768 chains); the other builds keep the logs inside the wave there.
+inline bool split_likelihood(int solver, bool arith_fma, size_t waves) {
+    return waves <= (size_t)SPLIT_LL_MAX_BLOCKS || (arith_fma && solver == 0);
+}
 #if defined(__HIPCC__)
 #define SEP_HOST_DEVICE __host__ __device__
 #else

@@ -44,6 +44,9 @@
 
 #include "sepaihrd_device.h"
 
+#ifndef SEPAIHRD_DOPRI5_WPS2
+#define SEPAIHRD_DOPRI5_WPS2 0
+#endif
 #ifndef SEPAIHRD_ARITH_FMA
 #error "compile with -DSEPAIHRD_ARITH_FMA=0 or 1"
 #endif
@@ -140,8 +143,17 @@ constexpr double db1 = 37.0 / 378 - 2825.0 / 27648, db3 = 250.0 / 621 - 18575.0 
 // ----------------------------------------------------------------------------------
 // per-lane model record
 // ----------------------------------------------------------------------------------
+#if SEPAIHRD_ARITH_FMA
+// tolerance mode folds per-chain constants once per evaluation instead of once per RHS call:
+//   MF_H_INFEC := h_infec / N, the contact row := a_i M(i, .), MF_R_I := gamma_I + h + d_community,
+//   MF_R_H := gamma_H + d_H + icu, MF_R_ICU := gamma_ICU + d_ICU  (8 instructions fewer per call)
+enum ModelField { MF_THETA = 0, MF_SIGMA, MF_GAMMA_P, MF_GAMMA_A, MF_GAMMA_I, MF_GAMMA_H, MF_GAMMA_ICU, MF_A,
+                  MF_H_INFEC, MF_P, MF_H, MF_ICU, MF_D_H, MF_D_ICU, MF_D_COMM, MF_INV_N, MF_R_I, MF_R_H, MF_R_ICU,
+                  MF_MROW0 };
+#else
 enum ModelField { MF_THETA = 0, MF_SIGMA, MF_GAMMA_P, MF_GAMMA_A, MF_GAMMA_I, MF_GAMMA_H, MF_GAMMA_ICU, MF_A,
                   MF_H_INFEC, MF_P, MF_H, MF_ICU, MF_D_H, MF_D_ICU, MF_D_COMM, MF_INV_N, MF_MROW0 };
+#endif
 template <int LPC>
 struct LaneModel {  // VGPR-resident (an LDS-resident variant measured no gain at 1 wave/SIMD and lost at 2)
     double v[MF_MROW0 + LPC];
@@ -156,14 +168,22 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
                                     double (&dx)[NUM_COMP], double beta_eff) {
     const double S = x[0], E = x[1], P = x[2], A = x[3], I = x[4], H = x[5], ICU = x[6];
     const double total_inf = P + A + q.get(MF_THETA) * I;
+#if SEPAIHRD_ARITH_FMA
+    const double inf_pressure = total_inf * q.get(MF_H_INFEC);  // h_infec / N folded
+#else
     const double inf_pressure = total_inf * q.get(MF_H_INFEC) * q.get(MF_INV_N);
+#endif
     // lambda_i = 0.0 + M(i,0) pi_0 + M(i,1) pi_1 + ..., j ascending (column-major walk of the reference).
     // The leading "0.0 +" only turns a -0.0 first product into +0.0, which max(0.0, .) below does anyway.
     double lambda = q.get(MF_MROW0) * group_bcast<LPC, 0>(inf_pressure);
     [&]<int... J>(std::integer_sequence<int, J...>) {
         ((lambda += q.get(MF_MROW0 + J + 1) * group_bcast<LPC, J + 1>(inf_pressure)), ...);
     }(std::make_integer_sequence<int, LPC - 1>{});
+#if SEPAIHRD_ARITH_FMA
+    lambda *= beta_eff;  // a_i folded into the contact row
+#else
     lambda *= beta_eff * q.get(MF_A);
+#endif
     const double lambda_val = (0.0 < lambda) ? lambda : 0.0;  // std::max(0.0, lambda)
 
     const double flow_SE = lambda_val * S;
@@ -174,18 +194,24 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     const double flow_IH = q.get(MF_H) * I;
     const double flow_IR = q.get(MF_GAMMA_I) * I;
     const double flow_ID_community = q.get(MF_D_COMM) * I;
-    const double I_out = flow_IR + flow_IH + flow_ID_community;
     const double flow_H_ICU = q.get(MF_ICU) * H;
-    const double H_out = q.get(MF_GAMMA_H) * H + q.get(MF_D_H) * H + flow_H_ICU;
-    const double ICU_out = (q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU)) * ICU;
 
     dx[0] = -flow_SE;
     dx[1] = flow_SE - flow_EP;
     dx[2] = flow_EP - flow_P_out;
     dx[3] = flow_PA - q.get(MF_GAMMA_A) * A;
+#if SEPAIHRD_ARITH_FMA
+    dx[4] = flow_PI - q.get(MF_R_I) * I;
+    dx[5] = flow_IH - q.get(MF_R_H) * H;
+    dx[6] = flow_H_ICU - q.get(MF_R_ICU) * ICU;
+#else
+    const double I_out = flow_IR + flow_IH + flow_ID_community;
+    const double H_out = q.get(MF_GAMMA_H) * H + q.get(MF_D_H) * H + flow_H_ICU;
+    const double ICU_out = (q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU)) * ICU;
     dx[4] = flow_PI - I_out;
     dx[5] = flow_IH - H_out;
     dx[6] = flow_H_ICU - ICU_out;
+#endif
     dx[7] = q.get(MF_GAMMA_A) * A + flow_IR + q.get(MF_GAMMA_H) * H + q.get(MF_GAMMA_ICU) * ICU;
     dx[8] = q.get(MF_D_H) * H + q.get(MF_D_ICU) * ICU + flow_ID_community;
     dx[9] = flow_IH;
@@ -418,8 +444,17 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     q.set(MF_D_COMM, vec_slot(VF_D_COMM));
     const double Ni = pb.N[age];
     q.set(MF_INV_N, (Ni > 1e-9) ? (1.0 / Ni) : 0.0);  // AgeSEPAIHRDModel.cpp:332-334
+#if SEPAIHRD_ARITH_FMA
+    q.set(MF_H_INFEC, q.get(MF_H_INFEC) * q.get(MF_INV_N));
+    q.set(MF_R_I, q.get(MF_GAMMA_I) + q.get(MF_H) + q.get(MF_D_COMM));
+    q.set(MF_R_H, q.get(MF_GAMMA_H) + q.get(MF_D_H) + q.get(MF_ICU));
+    q.set(MF_R_ICU, q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU));
+    SEP_UNROLL
+    for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, q.get(MF_A) * pb.Mrow[age * LPC + j]);
+#else
     SEP_UNROLL
     for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, pb.Mrow[age * LPC + j]);
+#endif
 
     // beta(t) kappa(t) on every merged segment: "current_beta * reduction_factor" of the RHS, once per chain
     Schedule sch;
@@ -814,12 +849,15 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 // obs log(sim + 1e-10) - (sim + 1e-10) for valid observations, summed over the ages of the chain in
 // ascending order (the reference's inner loop, SEPAIHRDObjectiveFunction.cpp:264-276).
 // ----------------------------------------------------------------------------------
+constexpr int LL_DAYS_PER_BLOCK = 4;  // one wave per day: fewer, larger workgroups for the dispatcher
 template <int LPC>
-__global__ __launch_bounds__(WAVE) void sepaihrd_ll_terms_kernel(const DevProblem pb, const int B,
-                                                                  const EvalOutputs out, const int cum_chains) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_kernel(const DevProblem pb, const int B,
+                                                                                    const EvalOutputs out,
+                                                                                    const int cum_chains) {
+    const int lane = threadIdx.x % WAVE;
     const size_t col = (size_t)blockIdx.x * WAVE + lane;  // chain * LPC + age
-    const int k = blockIdx.y;
+    const int k = blockIdx.y * LL_DAYS_PER_BLOCK + threadIdx.x / WAVE;
+    if (k >= pb.T) return;
     const size_t stride = (size_t)cum_chains * LPC;
     const size_t chain = col / LPC;
     const int age = (int)(col % LPC);
@@ -906,7 +944,8 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
                        st, pb, d_theta, B, out, cum_chains);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
-        hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, pb.T), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+        hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, (pb.T + LL_DAYS_PER_BLOCK - 1) / LL_DAYS_PER_BLOCK),
+                           dim3(WAVE * LL_DAYS_PER_BLOCK), 0, st, pb, B, out, cum_chains);
         hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -918,8 +957,9 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
-    if (blocks <= SPLIT_LL_MAX_BLOCKS || out.force_split) return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
-    if constexpr (SOLVER == 1) {
+    if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
+        return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
         // two waves per SIMD only pay when there are two waves for every SIMD
         if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
     }
