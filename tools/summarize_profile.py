@@ -3,17 +3,8 @@ import csv, glob, json, os, shutil, sys, collections
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(f"{src}/stats/*/*kernel_stats.csv"):
+for f in sorted(glob.glob(f"{src}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]:
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
-counters = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
-    for f in glob.glob(f"{src}/{d}/*/*counter_collection.csv"):
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if "sepaihrd_eval_kernel" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            counters[k] = sum(v) / len(v)
 bench = None
 try:
     for line in open(f"{src}/bench.json"):
@@ -21,6 +12,21 @@ try:
             bench = json.loads(line)
 except FileNotFoundError:
     pass
+# the bench also launches the OTHER arithmetic's kernel a few times: count only the measured one
+# (third template argument: 1 = fma, 0 = strict)
+arith_flag = "1" if (bench or {}).get("config", {}).get("arith", "fma") == "fma" else "0"
+import re
+pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + ",")
+counters = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
+    files = sorted(glob.glob(f"{src}/{d}/*/*counter_collection.csv"), key=os.path.getmtime)
+    for f in files[-1:]:  # newest run only: gpurun merges into an existing directory
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if pat.search(r["Kernel_Name"]):
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            counters[k] = sum(v) / len(v)
 out = {"tag": tag, "per_launch_counter_averages": counters,
        "units": "SQ_* cycle counters in quad-cycles; FETCH_SIZE / WRITE_SIZE in KiB (gfx950: FETCH_SIZE may "
                 "under-report wide loads by 2x, MI355X_MICROARCH.md HBM section)",
