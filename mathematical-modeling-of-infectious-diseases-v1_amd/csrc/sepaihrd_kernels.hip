@@ -65,6 +65,22 @@ __device__ __forceinline__ double dpp_move(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// row_newbcast (gfx90a+): lane LA of each 16-lane row into the lanes of banks BA, then (BB != 0) lane LB into
+// the lanes of banks BB; a bank = four adjacent lanes.  No LDS traffic and nothing to wait for, unlike
+// ds_bpermute behind __shfl (the n = 16 RHS did 32 of those per call with ~15 waits: LDS latency, not
+// arithmetic, set its pace).
+template <int LA, int BA, int LB, int BB>
+__device__ __forceinline__ double dpp_bcast_row(double v) {
+    const int slo = __double2loint(v), shi = __double2hiint(v);
+    int lo = __builtin_amdgcn_update_dpp(0, slo, 0x150 + LA, 0xf, BA, false);
+    int hi = __builtin_amdgcn_update_dpp(0, shi, 0x150 + LA, 0xf, BA, false);
+    if constexpr (BB != 0) {
+        lo = __builtin_amdgcn_update_dpp(lo, slo, 0x150 + LB, 0xf, BB, false);
+        hi = __builtin_amdgcn_update_dpp(hi, shi, 0x150 + LB, 0xf, BB, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
 // value held by lane J of my chain group
 template <int LPC, int J>
 __device__ __forceinline__ double group_bcast(double v) {
@@ -74,6 +90,11 @@ __device__ __forceinline__ double group_bcast(double v) {
         return dpp_move<(J) | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // quad_perm
     } else if constexpr (LPC == 4) {
         return dpp_move<J * 0x55>(v);  // quad_perm:[J,J,J,J]
+    } else if constexpr (LPC == 16) {
+        return dpp_bcast_row<J, 0xf, J, 0x0>(v);  // row_newbcast:J -- lane J of every 16-lane row
+    } else if constexpr (LPC == 8) {
+        // two chains per 16-lane row: banks 0-1 (lanes 0-7) take lane J, banks 2-3 (lanes 8-15) take lane 8+J
+        return dpp_bcast_row<J, 0x3, 8 + J, 0xc>(v);
     } else {
         return __shfl(v, J, LPC);
     }
@@ -92,6 +113,12 @@ __device__ __forceinline__ double group_max(double m) {
     } else if constexpr (LPC == 4) {
         m = max_keep(m, dpp_move<0xB1>(m));
         return max_keep(m, dpp_move<0x4E>(m));  // quad_perm:[2,3,0,1]
+    } else if constexpr (LPC == 8 || LPC == 16) {
+        m = max_keep(m, dpp_move<0xB1>(m));   // quad_perm:[1,0,3,2]
+        m = max_keep(m, dpp_move<0x4E>(m));   // quad_perm:[2,3,0,1]: every quad holds its max
+        m = max_keep(m, dpp_move<0x141>(m));  // row_half_mirror: lane i <-> 7 - i within each 8 lanes
+        if constexpr (LPC == 16) m = max_keep(m, dpp_move<0x140>(m));  // row_mirror: lane i <-> 15 - i
+        return m;
     } else {
 #pragma unroll
         for (int off = LPC / 2; off > 0; off >>= 1) m = max_keep(m, __shfl_xor(m, off));
