@@ -72,8 +72,10 @@ __device__ __forceinline__ double dpp_move(double v) {
 template <int LA, int BA, int LB, int BB>
 __device__ __forceinline__ double dpp_bcast_row(double v) {
     const int slo = __double2loint(v), shi = __double2hiint(v);
-    int lo = __builtin_amdgcn_update_dpp(0, slo, 0x150 + LA, 0xf, BA, false);
-    int hi = __builtin_amdgcn_update_dpp(0, shi, 0x150 + LA, 0xf, BA, false);
+    // first move into ALL banks (no "old" value to materialise), the second overwrites banks BB only
+    int lo = __builtin_amdgcn_mov_dpp(slo, 0x150 + LA, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(shi, 0x150 + LA, 0xf, 0xf, true);
+    (void)BA;
     if constexpr (BB != 0) {
         lo = __builtin_amdgcn_update_dpp(lo, slo, 0x150 + LB, 0xf, BB, false);
         hi = __builtin_amdgcn_update_dpp(hi, shi, 0x150 + LB, 0xf, BB, false);
