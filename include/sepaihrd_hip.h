@@ -181,7 +181,8 @@ int sepaihrd_eval_batch(sepaihrd_ctx *ctx, const double *theta, int B, double *l
  * (a hipStream_t, NULL = default stream).  No synchronisation.  The ctx-owned workspace
  * (D, CumH, CumICU of every chain at every output: T*3*n*8 bytes per chain) grows on the first call
  * for a larger batch; call sepaihrd_reserve first when the call must not allocate (stream capture).
- * Batches whose workspace would exceed 24 GiB are evaluated in chunks of chains on the same stream. */
+ * Batches whose workspace would exceed 24 GiB (environment SEPAIHRD_WORKSPACE_MB at sepaihrd_create
+ * overrides the budget) are evaluated in chunks of chains on the same stream. */
 int sepaihrd_eval_batch_device(sepaihrd_ctx *ctx, const double *d_theta, int B, double *d_loglik,
                                int32_t *d_status, int32_t *d_n_accept, int32_t *d_n_reject,
                                double *d_ll_parts, double *d_traj, void *stream);

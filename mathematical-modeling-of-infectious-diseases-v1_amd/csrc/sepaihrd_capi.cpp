@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -206,6 +207,10 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
     ctx->arith = pb->arith == SEPAIHRD_ARITH_FMA ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT;
     ctx->n = n; ctx->T = T; ctx->P = P;
     ctx->host_N.assign(pb->N, pb->N + n);
+    if (const char* mb = std::getenv("SEPAIHRD_WORKSPACE_MB")) {  // likelihood-workspace budget (default 24 GiB)
+        const long v = std::atol(mb);
+        if (v > 0) ctx->ws_budget_bytes = (size_t)v << 20;
+    }
 
     const int lpc = lanes_per_chain(n);
     const int ns = SS_SCHEDULE0 + nb + nk;

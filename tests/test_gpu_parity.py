@@ -228,3 +228,19 @@ def test_sixteen_age_classes_saturating_batch(mm, oracle_py, shipped):
     ref = oracle_py.Oracle(pb).eval_batch(theta[idx])
     assert np.array_equal(big["n_accept"][idx], ref["n_accept"])
     np.testing.assert_allclose(big["loglik"][idx], ref["loglik"], rtol=1e-10)
+
+
+def test_workspace_budget_chunks_give_the_same_bits(mm, synth400, draws, monkeypatch):
+    """A batch whose likelihood workspace exceeds the budget is evaluated in chunks of chains on the same
+    stream (default budget 24 GiB; SEPAIHRD_WORKSPACE_MB at context creation overrides it)."""
+    pb = synth400.with_(arith=mm.ARITH_FMA)
+    theta = draws(pb, 3000)                      # 3000 x 9.6 KB = 29 MB of workspace
+    whole = mm.HipObjective(pb).eval_batch(theta)
+    monkeypatch.setenv("SEPAIHRD_WORKSPACE_MB", "4")   # ~430 chains per chunk -> 7 chunks, the last one ragged
+    chunked = mm.HipObjective(pb)
+    monkeypatch.delenv("SEPAIHRD_WORKSPACE_MB")
+    got = chunked.eval_batch(theta)
+    for k in ("loglik", "status", "n_accept", "n_reject", "ll_parts"):
+        assert np.array_equal(got[k], whole[k]), k
+    traj = chunked.eval_batch(theta[:900], want_traj=True)["traj"]
+    assert np.array_equal(traj, mm.HipObjective(pb).eval_batch(theta[:900], want_traj=True)["traj"])
