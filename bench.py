@@ -136,10 +136,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # SEPAIHRD_BENCH_REHEARSAL=1: every rank on device 0 with the gloo backend -- exercises the multi-rank
+    # code path (sharded draws, barriers, max-reduction, rank-0 line) on a one-GPU box; not a measurement
+    rehearsal = os.environ.get("SEPAIHRD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import mmid_amd_loader
     mm = mmid_amd_loader.load()
@@ -198,7 +206,7 @@ def main():
     kernel_ms = tm["integrator_ms"] / max(tm["launches"], 1)      # dominant kernel: sepaihrd_eval_kernel
     ll_pass_ms = tm["likelihood_ms"] / max(tm["launches"], 1)     # ll_terms + ll_reduce (0 when inline)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed_max = float(el.item())
@@ -223,7 +231,7 @@ def main():
     hip.set_arith(pb.arith)
 
     allgather_ms = None
-    if args.allgather and world > 1:
+    if args.allgather and world > 1 and not rehearsal:
         # post-calibration ensemble summary record per chain: [P means | P variances |
         # best logpost | accept count] -- here filled with the chain's theta and log-likelihood
         rec = torch.zeros(B, 2 * P + 2, dtype=torch.float64, device=dev)
