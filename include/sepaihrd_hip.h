@@ -222,6 +222,11 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
  * reference's `if (!sim_result.isValid()) continue`.
  *   ppc_quantiles   [6][n_probs][T_pos][n_age]   T_pos = number of output times >= 0
  *   sero_quantiles  [n_probs][n_times] or NULL;  rt_quantiles  [n_probs][n_times] or NULL
+ *   metrics         [S][12 + 4 n_age] or NULL: the per-sample table of MetricsCalculator::calculateEssentialMetrics
+ *                   (src/model/MetricsCalculator.cpp:8-170) -- R0, overall_IFR, overall_attack_rate, peak_hospital,
+ *                   peak_ICU, time_to_peak_hospital, time_to_peak_ICU, total_deaths, max_Rt, min_Rt, final_Rt,
+ *                   seroprevalence at the output time closest to day 64, then per age IFR, IHR, IICUR, attack rate;
+ *                   NaN rows for skipped samples
  *   status          [S] integrator status per sample, or NULL;  n_valid: count of status 0, or NULL
  * S <= 16384 (one sorted segment lives in LDS); larger ensembles: SEPAIHRD_E_UNSUPPORTED. */
 #define SEPAIHRD_INIT_FROM_THETA 0
@@ -232,7 +237,7 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
 int sepaihrd_set_initial_state_mode(sepaihrd_ctx *ctx, int mode);
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, const double *probs,
                                 int n_probs, double *ppc_quantiles, double *sero_quantiles,
-                                double *rt_quantiles, int32_t *status, int32_t *n_valid);
+                                double *rt_quantiles, double *metrics, int32_t *status, int32_t *n_valid);
 
 /* ---- Adaptive-Metropolis chains with their state resident on the device ----
  *

@@ -535,8 +535,8 @@ int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
 }
 
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, const double* probs, int n_probs,
-                                double* ppc_quantiles, double* sero_quantiles, double* rt_quantiles, int32_t* status,
-                                int32_t* n_valid) {
+                                double* ppc_quantiles, double* sero_quantiles, double* rt_quantiles, double* metrics,
+                                int32_t* status, int32_t* n_valid) {
     if (!ctx) return SEPAIHRD_E_INVALID_ARG;
     if (S <= 0 || !theta || !probs || n_probs <= 0 || n_probs > 1024 || !ppc_quantiles) {
         ctx->last_error = "ensemble_quantiles: need S > 0, theta, probs (1..1024) and ppc_quantiles";
@@ -565,7 +565,8 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     int rc = ensure_workspace(ctx, chains);
     if (rc != SEPAIHRD_OK) return rc;
 
-    const bool want_sero = sero_quantiles != nullptr, want_rt = rt_quantiles != nullptr;
+    const bool want_sero = sero_quantiles != nullptr, want_metrics = metrics != nullptr;
+    const bool want_rt = rt_quantiles != nullptr || want_metrics;  // the metric table reads the Rt values
     const bool want_traj = want_sero || want_rt;
     if (want_rt && dp.n > 16) {
         ctx->last_error = "ensemble_quantiles: Rt trajectories are built for at most 16 age classes";
@@ -576,7 +577,9 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     const size_t n_rt = want_rt ? (size_t)n_probs * dp.T : 0;
     const size_t n_vals = ((size_t)6 * Tp * dp.n + (want_sero ? dp.T : 0) + (want_rt ? dp.T : 0)) * S_pad;
     const size_t n_traj = want_traj ? (size_t)S * dp.T * NUM_COMP * dp.n : 0;
-    double *d_theta = nullptr, *d_ll = nullptr, *d_vals = nullptr, *d_traj = nullptr, *d_probs = nullptr, *d_q = nullptr;
+    double *d_theta = nullptr, *d_ll = nullptr, *d_vals = nullptr, *d_traj = nullptr, *d_probs = nullptr, *d_q = nullptr,
+           *d_metrics = nullptr;
+    const size_t n_metrics = want_metrics ? (size_t)S * (12 + 4 * dp.n) : 0;
     int32_t* d_nv = nullptr;
     std::vector<void*> tmp;
     auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
@@ -588,7 +591,7 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     if (!dalloc((void**)&d_theta, (size_t)S * ctx->P * sizeof(double)) || !dalloc((void**)&d_ll, (size_t)S * sizeof(double)) ||
         !dalloc((void**)&d_vals, n_vals * sizeof(double)) || !dalloc((void**)&d_traj, n_traj * sizeof(double)) ||
         !dalloc((void**)&d_probs, (size_t)n_probs * sizeof(double)) || !dalloc((void**)&d_q, (n_ppc + n_sero + n_rt) * sizeof(double)) ||
-        !dalloc((void**)&d_nv, sizeof(int32_t))) {
+        !dalloc((void**)&d_nv, sizeof(int32_t)) || !dalloc((void**)&d_metrics, n_metrics * sizeof(double))) {
         cleanup();
         ctx->last_error = "ensemble_quantiles: device allocation failed";
         return SEPAIHRD_E_HIP;
@@ -619,6 +622,7 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     a.rt_segment0 = 6 * Tp * dp.n + (want_sero ? dp.T : 0);
     a.pb = &ctx->dp;
     a.theta = d_theta;
+    a.metrics_out = want_metrics ? d_metrics : nullptr;
     rc = launch_ensemble_summaries(a, nullptr);
     if (rc != 0) {
         cleanup();
@@ -630,8 +634,11 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     if (want_sero)
         HIP_TRY(hipMemcpy(sero_quantiles, d_q + n_ppc, n_sero * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 { cleanup(); return SEPAIHRD_E_HIP; });
-    if (want_rt)
+    if (rt_quantiles)
         HIP_TRY(hipMemcpy(rt_quantiles, d_q + n_ppc + n_sero, n_rt * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                { cleanup(); return SEPAIHRD_E_HIP; });
+    if (want_metrics)
+        HIP_TRY(hipMemcpy(metrics, d_metrics, n_metrics * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 { cleanup(); return SEPAIHRD_E_HIP; });
     if (status)
         HIP_TRY(hipMemcpy(status, ctx->ws_status, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,

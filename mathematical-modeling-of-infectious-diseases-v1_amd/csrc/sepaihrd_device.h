@@ -108,6 +108,7 @@ struct EnsembleArgs {
     int rt_segment0;
     const DevProblem* pb;     // host pointer to the ctx's problem (kernel argument by value)
     const double* theta;      // [S][P] device, the samples
+    double* metrics_out;      // [S][12 + 4 n] per-sample summary metrics, device or null (needs rt_out)
 };
 int launch_ensemble_summaries(const EnsembleArgs& a, void* stream);
 

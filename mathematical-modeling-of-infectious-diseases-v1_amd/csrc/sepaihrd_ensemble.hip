@@ -192,6 +192,134 @@ __global__ __launch_bounds__(WAVE) void ensemble_rt_kernel(const EnsembleArgs a,
     out[s] = lambda;
 }
 
+// Per-sample summary metrics, one thread per sample
+// (MetricsCalculator::calculateEssentialMetrics, src/model/MetricsCalculator.cpp:8-170).  Row layout:
+//   [0] R0  [1] overall_IFR  [2] overall_attack_rate  [3] peak_hospital  [4] peak_ICU
+//   [5] time_to_peak_hospital  [6] time_to_peak_ICU  [7] total_deaths  [8] max_Rt  [9] min_Rt  [10] final_Rt
+//   [11] seroprevalence at the output time closest to day 64, then per age: IFR, IHR, IICUR, attack rate
+// Quirks kept: cumulative infections = the non-S part of the initial state + sum_t lambda_t S_t dt with
+// lambda_t = beta kappa(t) M (P + A + theta I)/N using the CONSTANT beta (no schedule, no a_i, no h_infec) and
+// dt = 1 for the first time point (:103-113); max_Rt starts at 0, min_Rt at 1e6 (AnalysisTypes.hpp:26-27);
+// peaks move on strict ">" only (:91-98); ratios need more than one infection and are clipped to [0, 1]
+// (:139-157).  R0 = spectral radius of F V^-1 with S = N, beta(0), kappa(0) and no clipping of F (:22-52).
+constexpr int METRIC_SCALARS = 12;
+__global__ __launch_bounds__(WAVE) void ensemble_metrics_kernel(const EnsembleArgs a, const DevProblem pb, const double* theta) {
+    const int s = blockIdx.x * WAVE + threadIdx.x;
+    if (s >= a.S) return;
+    const int n = a.n, width = METRIC_SCALARS + 4 * n;
+    double* out = a.metrics_out + (size_t)s * width;
+    if (a.wstatus[s] != 0) {
+        for (int i = 0; i < width; ++i) out[i] = NAN;
+        return;
+    }
+    const double* th = theta + (size_t)s * pb.P;
+    const double beta_c = ens_scalar(pb, th, SS_BETA), theta_i = ens_scalar(pb, th, SS_THETA);
+    const double gamma_p = ens_scalar(pb, th, SS_GAMMA_P), gamma_A = ens_scalar(pb, th, SS_GAMMA_A),
+                 gamma_I = ens_scalar(pb, th, SS_GAMMA_I);
+    const double* traj = a.traj + (size_t)s * a.T * (NUM_COMP * n);
+    const double* rt = a.vals + (size_t)a.rt_segment0 * a.S_pad + s;  // Rt(s, k) at stride S_pad
+    double total_pop = 0.0;
+    for (int i = 0; i < n; ++i) total_pop += pb.N[i];
+
+    // R0
+    double r0 = 0.0;
+    {
+        int seg = 0;
+        for (int j = 0; j < pb.nm; ++j) seg += (pb.mends[j] < 0.0) ? 1 : 0;
+        const double beta0 = (pb.nb > 0) ? ens_scalar(pb, th, SS_SCHEDULE0 + pb.seg_ib[seg]) : beta_c;
+        const double kappa0 = ens_scalar(pb, th, SS_SCHEDULE0 + pb.nb + pb.seg_ik[seg]);
+        double ci[RT_MAX_AGE], gj[RT_MAX_AGE], v[RT_MAX_AGE], w[RT_MAX_AGE];
+        for (int i = 0; i < n; ++i) {
+            ci[i] = beta0 * kappa0 * ens_vec(pb, th, VF_A, i) * pb.N[i];
+            const double pj = ens_vec(pb, th, VF_P, i), hj = ens_vec(pb, th, VF_H, i);
+            const double dwell = 1.0 / gamma_p + pj / gamma_A + theta_i * (1.0 - pj) / (gamma_I + hj);
+            gj[i] = (pb.N[i] < 1e-9) ? 0.0 : ens_vec(pb, th, VF_H_INFEC, i) / pb.N[i] * dwell;
+            v[i] = 1.0;
+        }
+        for (int it = 0; it < 2000; ++it) {
+            double m = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j) acc += ci[i] * pb.Mrow[i * pb.lpc + j] * gj[j] * v[j];
+                w[i] = acc;
+                m = (fabs(acc) > m) ? fabs(acc) : m;
+            }
+            if (!(m > 0.0)) { r0 = 0.0; break; }
+            for (int i = 0; i < n; ++i) v[i] = w[i] / m;
+            const bool done = fabs(m - r0) <= 1e-15 * m;
+            r0 = m;
+            if (done) break;
+        }
+    }
+
+    double cum_inf[RT_MAX_AGE];
+    for (int i = 0; i < n; ++i) {
+        double c = 0.0;
+        for (int comp = 1; comp <= 7; ++comp) c += pb.init_state[comp * pb.lpc + i];  // E0 + P0 + ... + R0
+        cum_inf[i] = c;
+    }
+    int target = 0;
+    {
+        double best = INFINITY;
+        for (int k = 0; k < a.T; ++k) {
+            const double d = fabs(pb.times[k] - 64.0);
+            if (d < best) { best = d; target = k; }
+        }
+    }
+    double peak_h = 0.0, peak_icu = 0.0, t_peak_h = 0.0, t_peak_icu = 0.0;
+    double max_rt = 0.0, min_rt = 1e6, final_rt = 0.0, sero64 = 0.0;
+    for (int k = 0; k < a.T; ++k) {
+        const double* row = traj + (size_t)k * (NUM_COMP * n);
+        const double t = pb.times[k];
+        const double dt = (k > 0) ? (t - pb.times[k - 1]) : 1.0;
+        const double r = rt[(size_t)k * a.S_pad];
+        max_rt = (max_rt < r) ? r : max_rt;
+        min_rt = (r < min_rt) ? r : min_rt;
+        if (k == a.T - 1) final_rt = r;
+        double tot_h = 0.0, tot_icu = 0.0, tot_s = 0.0;
+        for (int i = 0; i < n; ++i) { tot_h += row[5 * n + i]; tot_icu += row[6 * n + i]; tot_s += row[i]; }
+        if (tot_h > peak_h) { peak_h = tot_h; t_peak_h = t; }
+        if (tot_icu > peak_icu) { peak_icu = tot_icu; t_peak_icu = t; }
+        int seg = 0;
+        for (int j = 0; j < pb.nm; ++j) seg += (pb.mends[j] < t) ? 1 : 0;
+        const double kappa = ens_scalar(pb, th, SS_SCHEDULE0 + pb.nb + pb.seg_ik[seg]);
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double load = (pb.N[j] > 1e-9) ? (row[2 * n + j] + row[3 * n + j] + theta_i * row[4 * n + j]) / pb.N[j] : 0.0;
+                acc += pb.Mrow[i * pb.lpc + j] * load;
+            }
+            cum_inf[i] += (beta_c * kappa) * acc * row[i] * dt;
+        }
+        if (k == target) sero64 = (total_pop - tot_s) / total_pop;
+    }
+    const double* last = traj + (size_t)(a.T - 1) * (NUM_COMP * n);
+    double sum_inf = 0.0, sum_deaths = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double deaths = last[8 * n + i] - pb.init_state[8 * pb.lpc + i];
+        const double hosp = last[9 * n + i] - pb.init_state[9 * pb.lpc + i];
+        const double icu = last[10 * n + i] - pb.init_state[10 * pb.lpc + i];
+        sum_inf += cum_inf[i];
+        sum_deaths += deaths;
+        double ifr = 0.0, ihr = 0.0, iicur = 0.0;
+        if (cum_inf[i] > 1.0) {
+            ifr = fmax(0.0, fmin(deaths / cum_inf[i], 1.0));
+            ihr = fmax(0.0, fmin(hosp / cum_inf[i], 1.0));
+            iicur = fmax(0.0, fmin(icu / cum_inf[i], 1.0));
+        }
+        out[METRIC_SCALARS + 4 * i + 0] = ifr;
+        out[METRIC_SCALARS + 4 * i + 1] = ihr;
+        out[METRIC_SCALARS + 4 * i + 2] = iicur;
+        out[METRIC_SCALARS + 4 * i + 3] = (pb.N[i] > 0) ? cum_inf[i] / pb.N[i] : 0.0;
+    }
+    out[0] = r0;
+    out[1] = (sum_inf > 1e-9) ? sum_deaths / sum_inf : 0.0;
+    out[2] = sum_inf / total_pop;
+    out[3] = peak_h; out[4] = peak_icu; out[5] = t_peak_h; out[6] = t_peak_icu;
+    out[7] = sum_deaths;
+    out[8] = max_rt; out[9] = min_rt; out[10] = final_rt; out[11] = sero64;
+}
+
 // Pass 2: one workgroup per segment; bitonic sort in LDS, then the interpolated quantiles.
 __global__ void ensemble_quantile_kernel(const EnsembleArgs a, const int n_series_segments) {
     extern __shared__ double seg[];
@@ -252,6 +380,10 @@ int launch_ensemble_summaries(const EnsembleArgs& a, void* stream) {
     if (rt) {
         const size_t cells = (size_t)a.S_pad * a.T;
         hipLaunchKernelGGL(ensemble_rt_kernel, dim3((unsigned)((cells + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a, *a.pb, a.theta);
+    }
+    if (a.metrics_out != nullptr) {
+        if (!rt) return -4;  // the table needs the Rt values
+        hipLaunchKernelGGL(ensemble_metrics_kernel, dim3((unsigned)((a.S + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a, *a.pb, a.theta);
     }
     const int segments = n_series_segments + (sero ? a.T : 0) + (rt ? a.T : 0);
     const int threads = a.S_pad / 2 < 1024 ? a.S_pad / 2 : 1024;

@@ -119,7 +119,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_mh_read_proposal.argtypes = [vp, vp]
     lib.sepaihrd_mh_history_length.argtypes = [vp]
     lib.sepaihrd_set_initial_state_mode.argtypes = [vp, C.c_int]
-    lib.sepaihrd_ensemble_quantiles.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.sepaihrd_ensemble_quantiles.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -253,7 +253,8 @@ class HipObjective:
         """0: x(t0) derived from theta (objective); 1: problem.initial_state as given (ensemble runs)."""
         self._check(self.lib.sepaihrd_set_initial_state_mode(self.ctx, int(mode)), "set_initial_state_mode")
 
-    def ensemble_quantiles(self, theta, probs, want_sero: bool = True, want_rt: bool = False) -> dict:
+    def ensemble_quantiles(self, theta, probs, want_sero: bool = True, want_rt: bool = False,
+                           want_metrics: bool = False) -> dict:
         """Posterior-ensemble summaries (ResultAggregator.cpp:297-345, MetricsCalculator.cpp:199-226):
         ppc [6][n_probs][T_pos][n], sero [n_probs][T], status [S], n_valid."""
         th = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
@@ -263,17 +264,20 @@ class HipObjective:
         ppc = np.empty((6, npb, Tp, self.pb.n))
         sero = np.empty((npb, self.pb.n_times)) if want_sero else None
         rt = np.empty((npb, self.pb.n_times)) if want_rt else None
+        met = np.empty((S, 12 + 4 * self.pb.n)) if want_metrics else None
         status = np.empty(S, dtype=np.int32)
         nv = C.c_int32(0)
         self._check(self.lib.sepaihrd_ensemble_quantiles(
             self.ctx, th.ctypes.data, S, pr.ctypes.data, npb, ppc.ctypes.data,
-            sero.ctypes.data if want_sero else None, rt.ctypes.data if want_rt else None, status.ctypes.data,
-            C.byref(nv)), "ensemble_quantiles")
+            sero.ctypes.data if want_sero else None, rt.ctypes.data if want_rt else None,
+            met.ctypes.data if want_metrics else None, status.ctypes.data, C.byref(nv)), "ensemble_quantiles")
         out = {"ppc": ppc, "status": status, "n_valid": nv.value}
         if want_sero:
             out["sero"] = sero
         if want_rt:
             out["rt"] = rt
+        if want_metrics:
+            out["metrics"] = met
         return out
 
     def reserve(self, max_B: int):

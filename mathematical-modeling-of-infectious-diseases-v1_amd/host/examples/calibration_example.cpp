@@ -100,10 +100,18 @@ int main() {
                     ppc.daily_hospitalizations.median(35, 3), ppc.daily_hospitalizations.lower_95(35, 3),
                     ppc.daily_hospitalizations.upper_95(35, 3), oH(35, 3), ppc.samples_used);
         std::printf("seroprevalence day 89    median %.5f\n", sero.at(89.0).at("median"));
+        const auto rt = ensemble.aggregateRt(calibrator.getMCMCSamples(), 40, 2);
+        const std::vector<EssentialMetrics> rows = ensemble.calculateEssentialMetrics(calibrator.getMCMCSamples(), 40, 2);
+        const auto summary = HipPosteriorEnsemble::aggregateMetrics(rows);
+        std::printf("Rt day 0 / day 89        median %.3f / %.3f\n", rt.at(0.0).at("median"), rt.at(89.0).at("median"));
+        std::printf("essential metrics        %zu rows; R0 median %.3f [%.3f, %.3f], peak hospital occupancy mean %.1f, IFR oldest group mean %.4f\n",
+                    rows.size(), summary.at("R0").at("median"), summary.at("R0").at("q025"), summary.at("R0").at("q975"),
+                    summary.at("peak_hospital").at("mean"), summary.at("IFR_age_3").at("mean"));
 
         const bool ok = std::isfinite(calibrator.getBestObjectiveValue()) &&
                         calibrator.getBestObjectiveValue() >= calibrator.getInitialObjectiveValue() &&
-                        ppc.samples_used == static_cast<int>(calibrator.getMCMCSamples().size());
+                        ppc.samples_used == static_cast<int>(calibrator.getMCMCSamples().size()) &&
+                        rows.size() == (calibrator.getMCMCSamples().size() - 40 + 1) / 2 && summary.at("R0").at("median") > 0.0;
         std::printf(ok ? "OK\n" : "FAILED\n");
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

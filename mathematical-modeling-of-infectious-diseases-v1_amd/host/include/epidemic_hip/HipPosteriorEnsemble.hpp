@@ -34,7 +34,15 @@ struct PosteriorPredictiveData {
     int samples_used = 0;  // simulations that were valid (build-side addition)
 };
 
-using AggregatedStats = std::map<std::string, double>;  // "median", "q025", "q975", "q05", "q95"
+using AggregatedStats = std::map<std::string, double>;  // "median", "q025", "q975", "q05", "q95" (+ "mean", "std_dev")
+
+// include/model/AnalysisTypes.hpp:14-39 (kappa_values omitted: they are the sample's own parameters)
+struct EssentialMetrics {
+    double R0 = 0.0, overall_IFR = 0.0, overall_attack_rate = 0.0, peak_hospital_occupancy = 0.0, peak_ICU_occupancy = 0.0,
+           time_to_peak_hospital = 0.0, time_to_peak_ICU = 0.0, total_cumulative_deaths = 0.0;
+    double max_Rt = 0.0, min_Rt = 1e6, final_Rt = 0.0, seroprevalence_at_target_day = 0.0;
+    std::vector<double> age_specific_IFR, age_specific_IHR, age_specific_IICUR, age_specific_attack_rate;
+};
 
 class HipPosteriorEnsemble {
 public:
@@ -58,6 +66,13 @@ public:
     // PostCalibrationAnalyser.cpp:233-236,342; MetricsCalculator::calculateRtTrajectory :172-197)
     std::map<double, AggregatedStats> aggregateRt(const std::vector<Eigen::VectorXd>& param_samples, int burn_in,
                                                   int thinning);
+    // one EssentialMetrics row per valid simulation of the same samples (MetricsCalculator.cpp:8-170: what the
+    // reference writes to mcmc_batches/batch_k.csv), and its summary table with the metric names of
+    // ResultAggregator::aggregateBatchMetrics (:35-85): mean, std_dev, exact median / q025 / q975 over ALL rows
+    // instead of P^2 per batch pooled by aggregateAllBatches (:87-172)
+    std::vector<EssentialMetrics> calculateEssentialMetrics(const std::vector<Eigen::VectorXd>& param_samples, int burn_in,
+                                                            int thinning);
+    static std::map<std::string, AggregatedStats> aggregateMetrics(const std::vector<EssentialMetrics>& rows);
 
 private:
     void run(const std::vector<double>& thetas, int S, bool want_sero);
@@ -67,7 +82,8 @@ private:
     SimulationCache cache_;
     std::unique_ptr<HipSEPAIHRDObjectiveFunction> objective_;
     int n_ = 0, t_pos_ = 0;
-    std::vector<double> ppc_, sero_, rt_;  // [6][5][T_pos][n], [5][T], [5][T]
+    std::vector<double> ppc_, sero_, rt_, metrics_;  // [6][5][T_pos][n], [5][T], [5][T], [S][12 + 4 n]
+    int metrics_rows_ = 0;
     int n_valid_ = 0;
 };
 

@@ -1,6 +1,9 @@
 // host/src/HipPosteriorEnsemble.cpp -- see the header for the reference lines mirrored.
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 
+#include <algorithm>
+#include <cmath>
+#include <functional>
 #include <numeric>
 #include <random>
 
@@ -52,8 +55,11 @@ void HipPosteriorEnsemble::run(const std::vector<double>& thetas, int S, bool wa
     sero_.assign(want_sero ? static_cast<size_t>(5) * time_points_.size() : 0, 0.0);
     int32_t nv = 0;
     rt_.assign(want_sero ? static_cast<size_t>(5) * time_points_.size() : 0, 0.0);
+    metrics_.assign(want_sero ? static_cast<size_t>(S) * (12 + 4 * n_) : 0, 0.0);
+    metrics_rows_ = want_sero ? S : 0;
     const int rc = sepaihrd_ensemble_quantiles(ctx, thetas.data(), S, kProbs, 5, ppc_.data(),
-                                               want_sero ? sero_.data() : nullptr, want_sero ? rt_.data() : nullptr, nullptr, &nv);
+                                               want_sero ? sero_.data() : nullptr, want_sero ? rt_.data() : nullptr,
+                                               want_sero ? metrics_.data() : nullptr, nullptr, &nv);
     if (rc != SEPAIHRD_OK)
         throw ModelException("HipPosteriorEnsemble", std::string("sepaihrd_ensemble_quantiles: ") + sepaihrd_last_error(ctx));
     n_valid_ = nv;
@@ -134,6 +140,77 @@ std::map<double, AggregatedStats> HipPosteriorEnsemble::aggregateRt(const std::v
         out[time_points_[k]] = st;
     }
     return out;
+}
+
+std::vector<EssentialMetrics> HipPosteriorEnsemble::calculateEssentialMetrics(
+    const std::vector<Eigen::VectorXd>& param_samples, int burn_in, int thinning) {
+    std::vector<EssentialMetrics> out;
+    if (aggregateSeroprevalence(param_samples, burn_in, thinning).empty()) return out;  // same launch fills the table
+    const size_t width = static_cast<size_t>(12 + 4 * n_);
+    for (int s = 0; s < metrics_rows_; ++s) {
+        const double* r = &metrics_[static_cast<size_t>(s) * width];
+        if (std::isnan(r[0])) continue;  // invalid simulation: skipped (PostCalibrationAnalyser.cpp:222-226)
+        EssentialMetrics m;
+        m.R0 = r[0]; m.overall_IFR = r[1]; m.overall_attack_rate = r[2]; m.peak_hospital_occupancy = r[3];
+        m.peak_ICU_occupancy = r[4]; m.time_to_peak_hospital = r[5]; m.time_to_peak_ICU = r[6];
+        m.total_cumulative_deaths = r[7]; m.max_Rt = r[8]; m.min_Rt = r[9]; m.final_Rt = r[10];
+        m.seroprevalence_at_target_day = r[11];
+        for (int a = 0; a < n_; ++a) {
+            m.age_specific_IFR.push_back(r[12 + 4 * a + 0]);
+            m.age_specific_IHR.push_back(r[12 + 4 * a + 1]);
+            m.age_specific_IICUR.push_back(r[12 + 4 * a + 2]);
+            m.age_specific_attack_rate.push_back(r[12 + 4 * a + 3]);
+        }
+        out.push_back(std::move(m));
+    }
+    return out;
+}
+
+std::map<std::string, AggregatedStats> HipPosteriorEnsemble::aggregateMetrics(const std::vector<EssentialMetrics>& rows) {
+    std::map<std::string, AggregatedStats> result;
+    if (rows.empty()) return result;
+    const int n = static_cast<int>(rows[0].age_specific_IFR.size());
+    std::vector<std::pair<std::string, std::function<double(const EssentialMetrics&)>>> cols = {
+        {"R0", [](const EssentialMetrics& m) { return m.R0; }},
+        {"overall_IFR", [](const EssentialMetrics& m) { return m.overall_IFR; }},
+        {"overall_attack_rate", [](const EssentialMetrics& m) { return m.overall_attack_rate; }},
+        {"peak_hospital", [](const EssentialMetrics& m) { return m.peak_hospital_occupancy; }},
+        {"peak_ICU", [](const EssentialMetrics& m) { return m.peak_ICU_occupancy; }},
+        {"time_to_peak_hospital", [](const EssentialMetrics& m) { return m.time_to_peak_hospital; }},
+        {"time_to_peak_ICU", [](const EssentialMetrics& m) { return m.time_to_peak_ICU; }},
+        {"total_deaths", [](const EssentialMetrics& m) { return m.total_cumulative_deaths; }},
+        {"max_Rt", [](const EssentialMetrics& m) { return m.max_Rt; }},
+        {"min_Rt", [](const EssentialMetrics& m) { return m.min_Rt; }},
+        {"final_Rt", [](const EssentialMetrics& m) { return m.final_Rt; }},
+        {"seroprevalence_day64", [](const EssentialMetrics& m) { return m.seroprevalence_at_target_day; }}};
+    for (int a = 0; a < n; ++a) {
+        cols.push_back({"IFR_age_" + std::to_string(a), [a](const EssentialMetrics& m) { return m.age_specific_IFR[static_cast<size_t>(a)]; }});
+        cols.push_back({"IHR_age_" + std::to_string(a), [a](const EssentialMetrics& m) { return m.age_specific_IHR[static_cast<size_t>(a)]; }});
+        cols.push_back({"IICUR_age_" + std::to_string(a), [a](const EssentialMetrics& m) { return m.age_specific_IICUR[static_cast<size_t>(a)]; }});
+        cols.push_back({"AttackRate_age_" + std::to_string(a), [a](const EssentialMetrics& m) { return m.age_specific_attack_rate[static_cast<size_t>(a)]; }});
+    }
+    auto quantile = [](const std::vector<double>& v, double q) {  // PostCalibrationAnalyser.cpp:316-326
+        const double pos = q * (v.size() - 1);
+        const size_t idx = static_cast<size_t>(pos);
+        const double frac = pos - idx;
+        return idx + 1 < v.size() ? v[idx] * (1.0 - frac) + v[idx + 1] * frac : v[idx];
+    };
+    for (const auto& col : cols) {
+        std::vector<double> v;
+        for (const EssentialMetrics& m : rows) v.push_back(col.second(m));
+        double mean = 0.0;
+        for (double x : v) mean += x;
+        mean /= v.size();
+        double var = 0.0;  // ba::variance(lazy): the population variance
+        for (double x : v) var += (x - mean) * (x - mean);
+        var /= v.size();
+        std::sort(v.begin(), v.end());
+        AggregatedStats st;
+        st["mean"] = mean; st["std_dev"] = std::sqrt(var);
+        st["median"] = quantile(v, 0.5); st["q025"] = quantile(v, 0.025); st["q975"] = quantile(v, 0.975);
+        result[col.first] = st;
+    }
+    return result;
 }
 
 }  // namespace epidemic

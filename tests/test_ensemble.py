@@ -201,3 +201,26 @@ def test_hip_rt_trajectory_quantiles(mm, oracle_py, shipped, solver):
     assert np.array_equal(plain["ppc"], got["ppc"]) and np.array_equal(plain["sero"], got["sero"])
     only_rt = hip.ensemble_quantiles(theta, PROBS, want_sero=False, want_rt=True)
     assert np.array_equal(only_rt["rt"], got["rt"])
+
+
+@pytest.mark.gpu
+def test_hip_essential_metrics_table(mm, oracle_py, shipped):
+    """Per-sample EssentialMetrics rows of the device ensemble against the numpy restatement of
+    MetricsCalculator::calculateEssentialMetrics on the oracle's trajectories."""
+    import rt_numpy
+    pb = shipped.with_(arith=mm.ARITH_STRICT)
+    S = 12
+    theta = _draws(oracle_py, pb, S)
+    orc = oracle_py.Oracle(pb)
+    sim = orc.simulate_samples(theta)
+    ref = np.array([rt_numpy.essential_metrics(sim["traj"][s], orc.model_parameters(theta[s]), pb) for s in range(S)])
+    hip = mm.HipObjective(pb)
+    hip.set_initial_state_mode(1)
+    got = hip.ensemble_quantiles(theta, PROBS, want_sero=True, want_rt=True, want_metrics=True)["metrics"]
+    assert got.shape == ref.shape == (S, 12 + 4 * pb.n)
+    # columns 5, 6 are output times (exact); the rest are sums over 326 output rows of 1e-13-accurate states
+    assert np.array_equal(got[:, 5:7], ref[:, 5:7])
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+    assert np.all(ref[:, 0] > 1.0) and np.all((ref[:, 11] > 0) & (ref[:, 11] < 0.2))  # R0 > 1, plausible seroprevalence
+    only = hip.ensemble_quantiles(theta, PROBS, want_sero=False, want_rt=False, want_metrics=True)["metrics"]
+    assert np.array_equal(only, got)
