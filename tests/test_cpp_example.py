@@ -23,3 +23,26 @@ def test_cpp_calibration_example_runs_on_the_device():
     initial = float(lines[0].split()[-1])
     best = float([ln for ln in lines if ln.startswith("best after MCMC")][0].split()[3])
     assert best > initial
+
+
+@pytest.mark.gpu
+def test_end_to_end_calibration_driver(tmp_path):
+    """tools/run_calibration.py: two-phase calibration -> posterior trace files in the sampler's CSV format ->
+    post-calibration ensemble files, on the shipped problem with short settings."""
+    import csv
+    import json
+    import sys
+    out = tmp_path / "run"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_calibration.py"), "--out", str(out), "--chains", "4",
+                        "--hc-iterations", "6", "--hc-threads", "4", "--cloud-size-multiplier", "2", "--mcmc-iterations", "200",
+                        "--burn-in", "60", "--adaptation-period", "40", "--thinning", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["best_value"] >= summary["phase1_best_value"] >= summary["initial_value"]
+    assert summary["ensemble_valid"] == summary["ensemble_samples"] > 0
+    rows = list(csv.reader(open(out / "posterior_trace_chain0.csv")))
+    assert rows[0][:2] == ["iter", "log_posterior"] and len(rows[0]) == 2 + 62 and len(rows) == 1 + 50
+    rt = list(csv.reader(open(out / "Rt_aggregated_with_uncertainty.csv")))
+    assert len(rt) == 1 + 326 and float(rt[1][3]) > 1.0 > float(rt[-1][3]) * 0.5
+    assert len(list(csv.reader(open(out / "essential_metrics.csv")))) == 1 + summary["ensemble_samples"]
