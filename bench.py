@@ -74,6 +74,16 @@ def host_cpu_share(omp_max):
     return max(1, min(n, int(env_cap)) if env_cap else n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pb, theta, budget_s):
     """Oracle (CPU restatement of the reference path, kind "port") on a bounded sample of the
     same draws, OpenMP over chains on all host cores.  Checker only: never the measured path."""
@@ -103,6 +113,7 @@ def cpu_baseline(pb, theta, budget_s):
                   f"draws, {dt:.1f} s), oracle/liboracle.so (g++ -O3 -DNDEBUG, no -march=native, no FMA), "
                   f"OpenMP over chains on {cores} threads; single thread: {n1 / dt1:.1f} evals/s",
         "single_thread_value": n1 / dt1,
+        "cpu_model": cpu_model(), "nproc": os.cpu_count(), "omp_max_threads": oracle_py.load().oracle_num_threads(),
     }
 
 
