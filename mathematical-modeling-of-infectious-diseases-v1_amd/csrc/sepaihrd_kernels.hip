@@ -892,6 +892,15 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     const int age = (int)(col % LPC);
     const bool valid = chain < (size_t)B;
     const size_t c = valid ? col : 0;
+    if (k < pb.runup_offset) {  // outputs before t = 0 carry no observation: every term is 0 (wave-uniform)
+        if (valid && age == 0) {
+            double* dst = out.rows + (size_t)k * 3 * cum_chains + chain;
+            dst[0] = 0.0;
+            dst[cum_chains] = 0.0;
+            dst[2 * (size_t)cum_chains] = 0.0;
+        }
+        return;
+    }
     const double* cur = out.cum + (size_t)k * 3 * stride + c;
     const double* rec = pb.grid + ((size_t)k * LPC + age) * 4;  // {obs_H, obs_ICU, obs_D, t_{k+1}}
     double rs[3];
