@@ -879,6 +879,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 // ascending order (the reference's inner loop, SEPAIHRDObjectiveFunction.cpp:264-276).
 // ----------------------------------------------------------------------------------
 constexpr int LL_DAYS_PER_BLOCK = 4;  // one wave per day: fewer, larger workgroups for the dispatcher
+constexpr int LL_SERIAL_MIN_WAVES = 768;  // (chain, stream) lanes needed before the serial walk fills the chip
 template <int LPC>
 __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_kernel(const DevProblem pb, const int B,
                                                                                     const EvalOutputs out,
@@ -927,12 +928,70 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     }
 }
 
+// Likelihood pass for saturating batches: one lane per (chain, stream) walks the days and, within a day, the
+// ages -- the reference's two nested serial sums -- so there is no cross-lane traffic and no rows[] round trip;
+// the increments of all ages of a chain arrive in one vector load, the observations are wave-uniform
+// (scalar loads).  Needs >= 768 waves of chains to fill the chip (below that the (chain, day, age)-parallel
+// kernel above is faster); same operations in the same order, so the same bits.  The stream's sum goes to
+// rows[0][stream][chain] and the reduce kernel finishes with n_rows = 1.
+template <int LPC>
+__global__ __launch_bounds__(WAVE) void sepaihrd_ll_serial_kernel(const DevProblem pb, const int B, const EvalOutputs out,
+                                                                   const int cum_chains) {
+    const int chain = blockIdx.x * WAVE + threadIdx.x;
+    const int s = blockIdx.y;  // stream: H, ICU, D
+    const bool valid = chain < B;
+    const size_t c = valid ? (size_t)chain : 0;
+    const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU
+    const size_t stride = (size_t)cum_chains * LPC;
+    const double* cur = out.cum + (size_t)comp * stride + c * LPC;
+    double acc = 0.0;
+    // the sums are a dependent chain, the loads are not: DAYS days of increments are requested at a time
+    constexpr int DAYS = (LPC <= 4) ? 8 : (LPC == 8 ? 4 : 2);
+    for (int k0 = pb.runup_offset; k0 < pb.T; k0 += DAYS) {
+        double inc[DAYS][LPC];
+        SEP_UNROLL
+        for (int d = 0; d < DAYS; ++d) {
+            const int k = (k0 + d < pb.T) ? k0 + d : pb.T - 1;
+            const double* row = cur + (size_t)k * 3 * stride;
+            if constexpr (LPC % 4 == 0) {
+                SEP_UNROLL
+                for (int a = 0; a < LPC; a += 4) {
+                    const double4 v = *reinterpret_cast<const double4*>(row + a);
+                    inc[d][a] = v.x; inc[d][a + 1] = v.y; inc[d][a + 2] = v.z; inc[d][a + 3] = v.w;
+                }
+            } else {
+                SEP_UNROLL
+                for (int a = 0; a < LPC; ++a) inc[d][a] = row[a];
+            }
+        }
+        SEP_UNROLL
+        for (int d = 0; d < DAYS; ++d) {
+            const int k = k0 + d;
+            if (k >= pb.T) break;
+            const double* rec = pb.grid + (size_t)k * LPC * 4 + s;  // obs of age a at rec[4 a]: uniform over the wave
+            double r = 0.0;
+            SEP_UNROLL
+            for (int a = 0; a < LPC; ++a) {
+                const double x = (inc[d][a] < 0.0) ? 0.0 : inc[d][a];  // cwiseMax(0.0)
+                const double obs = rec[4 * a];
+                const double sim = x + 1e-10;
+                const double v = obs * log_pos(sim) - sim;
+                const double tv = (obs >= 0.0 && isfinite(obs)) ? v : 0.0;
+                r = (a == 0) ? tv : r + tv;  // "0.0 +" dropped: value-identical
+            }
+            acc += r;
+        }
+    }
+    if (valid) out.rows[(size_t)s * cum_chains + chain] = acc;
+}
+
 // Likelihood pass 2: one lane per (chain, stream) adds the daily row sums in day order (the serial
 // "log_likelihood += row_sum" of the reference) and lane 0 of each triple forms
 // total = (hosp + icu) + deaths; NaN / Inf -> lowest() (SEPAIHRDObjectiveFunction.cpp:222-227).
 // The additions are a dependent chain, the loads are not: 16 days are requested at a time.
 __global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProblem pb, const int B,
-                                                                   const EvalOutputs out, const int cum_chains) {
+                                                                   const EvalOutputs out, const int cum_chains,
+                                                                   const int n_rows) {
     // lane = 4 * chain_in_block + stream (stream 3 idles): 16 chains per wave, quad = one chain
     const int lane = threadIdx.x;
     const int stream = lane & 3;
@@ -943,14 +1002,14 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProbl
     const size_t step = (size_t)3 * cum_chains;
     double acc = 0.0;
     int k = 0;
-    for (; k + 16 <= pb.T; k += 16) {
+    for (; k + 16 <= n_rows; k += 16) {
         double v[16];
         SEP_UNROLL
         for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(k + j) * step];
         SEP_UNROLL
         for (int j = 0; j < 16; ++j) acc += v[j];
     }
-    for (; k < pb.T; ++k) acc += src[(size_t)k * step];
+    for (; k < n_rows; ++k) acc += src[(size_t)k * step];
     const double h = group_bcast<4, 0>(acc), i = group_bcast<4, 1>(acc), d = group_bcast<4, 2>(acc);
     if (!(chain < B) || stream != 0) return;
     int status = out.wstatus[chain];
@@ -982,9 +1041,15 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
                        st, pb, d_theta, B, out, cum_chains);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
-        hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, (pb.T + LL_DAYS_PER_BLOCK - 1) / LL_DAYS_PER_BLOCK),
-                           dim3(WAVE * LL_DAYS_PER_BLOCK), 0, st, pb, B, out, cum_chains);
-        hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+        if ((B + WAVE - 1) / WAVE >= LL_SERIAL_MIN_WAVES / 3) {
+            hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC>), dim3((B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out,
+                               cum_chains);
+            hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains, 1);
+        } else {
+            hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, (pb.T + LL_DAYS_PER_BLOCK - 1) / LL_DAYS_PER_BLOCK),
+                               dim3(WAVE * LL_DAYS_PER_BLOCK), 0, st, pb, B, out, cum_chains);
+            hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains, pb.T);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
