@@ -244,3 +244,34 @@ def test_workspace_budget_chunks_give_the_same_bits(mm, synth400, draws, monkeyp
         assert np.array_equal(got[k], whole[k]), k
     traj = chunked.eval_batch(theta[:900], want_traj=True)["traj"]
     assert np.array_equal(traj, mm.HipObjective(pb).eval_batch(theta[:900], want_traj=True)["traj"])
+
+
+def test_device_entry_point_is_graph_capturable(mm, synth400, draws):
+    """sepaihrd_eval_batch_device neither synchronises nor allocates once sepaihrd_reserve has covered the batch:
+    its three launches can be captured into a HIP graph and replayed on new inputs in the same buffers."""
+    import torch
+    pb = synth400.with_(arith=mm.ARITH_FMA)
+    B = 512
+    th_a, th_b = draws(pb, B, seed0=1), draws(pb, B, seed0=5000)
+    hip = mm.HipObjective(pb)
+    want_a, want_b = hip.eval_batch(th_a)["loglik"], hip.eval_batch(th_b)["loglik"]
+    hip.reserve(B)
+    d_theta = torch.from_numpy(th_a).cuda()
+    d_ll = torch.zeros(B, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip.eval_batch_device(d_theta, d_ll, stream=side.cuda_stream)  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        hip.eval_batch_device(d_theta, d_ll, stream=torch.cuda.current_stream().cuda_stream)
+    d_ll.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ll.cpu().numpy(), want_a)
+    d_theta.copy_(torch.from_numpy(th_b).cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ll.cpu().numpy(), want_b)
