@@ -228,7 +228,8 @@ int sepaihrd_reserve(sepaihrd_ctx *ctx, int max_B);
  *                   seroprevalence at the output time closest to day 64, then per age IFR, IHR, IICUR, attack rate;
  *                   NaN rows for skipped samples
  *   status          [S] integrator status per sample, or NULL;  n_valid: count of status 0, or NULL
- * S <= 16384 (one sorted segment lives in LDS); larger ensembles: SEPAIHRD_E_UNSUPPORTED. */
+ * Up to 16384 samples a segment is sorted in LDS; larger ensembles sort their segments in global memory
+ * (library segmented radix sort), sized only by HBM: 6 T_pos n_age + 2 n_times segments of S doubles. */
 #define SEPAIHRD_INIT_FROM_THETA 0
 #define SEPAIHRD_INIT_FIXED 1
 /* the finite-difference objective's rule (SEPAIHRDGradientObjectiveFunction.cpp:55-99): always scale

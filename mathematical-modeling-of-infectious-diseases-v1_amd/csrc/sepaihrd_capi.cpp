@@ -542,10 +542,6 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
         ctx->last_error = "ensemble_quantiles: need S > 0, theta, probs (1..1024) and ppc_quantiles";
         return SEPAIHRD_E_INVALID_ARG;
     }
-    if (S > ENSEMBLE_MAX_SAMPLES) {
-        ctx->last_error = "ensemble_quantiles: at most 16384 samples per call (sorted segment lives in LDS)";
-        return SEPAIHRD_E_UNSUPPORTED;
-    }
     for (int p = 0; p < n_probs; ++p)
         if (!(probs[p] >= 0.0 && probs[p] <= 1.0)) {
             ctx->last_error = "ensemble_quantiles: probabilities must lie in [0, 1]";
@@ -559,7 +555,9 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
         return SEPAIHRD_E_INVALID_ARG;
     }
     int S_pad = WAVE;
-    while (S_pad < S) S_pad <<= 1;
+    while (S_pad < S && S_pad < ENSEMBLE_MAX_SAMPLES) S_pad <<= 1;
+    const bool big = S > ENSEMBLE_MAX_SAMPLES;  // segments sorted in global memory instead of LDS
+    if (big) S_pad = (S + WAVE - 1) / WAVE * WAVE;
     const size_t cpw = (size_t)(WAVE / dp.lpc);
     const size_t chains = ((size_t)S + cpw - 1) / cpw * cpw;
     int rc = ensure_workspace(ctx, chains);
@@ -578,7 +576,9 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     const size_t n_vals = ((size_t)6 * Tp * dp.n + (want_sero ? dp.T : 0) + (want_rt ? dp.T : 0)) * S_pad;
     const size_t n_traj = want_traj ? (size_t)S * dp.T * NUM_COMP * dp.n : 0;
     double *d_theta = nullptr, *d_ll = nullptr, *d_vals = nullptr, *d_traj = nullptr, *d_probs = nullptr, *d_q = nullptr,
-           *d_metrics = nullptr;
+           *d_metrics = nullptr, *d_scratch = nullptr;
+    // scratch of the global sort: up to 2 GiB, at least one segment
+    const size_t n_scratch = big ? std::max<size_t>((size_t)S_pad, std::min<size_t>(n_vals, (size_t)1 << 28) / S_pad * S_pad) : 0;
     const size_t n_metrics = want_metrics ? (size_t)S * (12 + 4 * dp.n) : 0;
     int32_t* d_nv = nullptr;
     std::vector<void*> tmp;
@@ -591,7 +591,8 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     if (!dalloc((void**)&d_theta, (size_t)S * ctx->P * sizeof(double)) || !dalloc((void**)&d_ll, (size_t)S * sizeof(double)) ||
         !dalloc((void**)&d_vals, n_vals * sizeof(double)) || !dalloc((void**)&d_traj, n_traj * sizeof(double)) ||
         !dalloc((void**)&d_probs, (size_t)n_probs * sizeof(double)) || !dalloc((void**)&d_q, (n_ppc + n_sero + n_rt) * sizeof(double)) ||
-        !dalloc((void**)&d_nv, sizeof(int32_t)) || !dalloc((void**)&d_metrics, n_metrics * sizeof(double))) {
+        !dalloc((void**)&d_nv, sizeof(int32_t)) || !dalloc((void**)&d_metrics, n_metrics * sizeof(double)) ||
+        !dalloc((void**)&d_scratch, n_scratch * sizeof(double))) {
         cleanup();
         ctx->last_error = "ensemble_quantiles: device allocation failed";
         return SEPAIHRD_E_HIP;
@@ -623,6 +624,8 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     a.pb = &ctx->dp;
     a.theta = d_theta;
     a.metrics_out = want_metrics ? d_metrics : nullptr;
+    a.sort_scratch = big ? d_scratch : nullptr;
+    a.sort_scratch_doubles = n_scratch;
     rc = launch_ensemble_summaries(a, nullptr);
     if (rc != 0) {
         cleanup();

@@ -89,7 +89,7 @@ int kernel_info_fma(const DevProblem& pb, int solver, LaunchInfo* info);
 // ---- posterior ensemble summaries (csrc/sepaihrd_ensemble.hip) ----
 constexpr int ENSEMBLE_MAX_SAMPLES = 16384;  // one sorted segment lives in LDS (128 KiB of 160 KiB)
 struct EnsembleArgs {
-    int S, S_pad;             // samples, padded to a power of two >= 64
+    int S, S_pad;             // samples; stride of a segment: a power of two >= 64 (LDS sort) or a multiple of 64
     int lpc, n, T, Tp;        // lanes per chain, ages, output times, output times with t >= 0
     int runup_offset;         // index of the first output time >= 0
     int n_probs;
@@ -109,6 +109,9 @@ struct EnsembleArgs {
     const DevProblem* pb;     // host pointer to the ctx's problem (kernel argument by value)
     const double* theta;      // [S][P] device, the samples
     double* metrics_out;      // [S][12 + 4 n] per-sample summary metrics, device or null (needs rt_out)
+    // ensembles beyond the LDS sort (S_pad > ENSEMBLE_MAX_SAMPLES): scratch for groups of globally sorted segments
+    double* sort_scratch;
+    size_t sort_scratch_doubles;
 };
 int launch_ensemble_summaries(const EnsembleArgs& a, void* stream);
 

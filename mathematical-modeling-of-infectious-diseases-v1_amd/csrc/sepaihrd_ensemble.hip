@@ -28,6 +28,11 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
 #include "sepaihrd_device.h"
 
 namespace sepaihrd {
@@ -320,6 +325,29 @@ __global__ __launch_bounds__(WAVE) void ensemble_metrics_kernel(const EnsembleAr
     out[8] = max_rt; out[9] = min_rt; out[10] = final_rt; out[11] = sero64;
 }
 
+// quantile p of sorted segment `sid` (nv valid values first, +inf after them) into its output slot
+__device__ __forceinline__ void write_quantile(const EnsembleArgs& a, int n_series_segments, size_t sid, int p, int nv,
+                                               const double* seg) {
+    double r = NAN;
+    if (nv > 0) {
+        const double pos = a.probs[p] * (double)(size_t)(nv - 1);
+        const size_t idx = (size_t)pos;
+        const double frac = pos - (double)idx;
+        r = (idx + 1 < (size_t)nv) ? seg[idx] * (1.0 - frac) + seg[idx + 1] * frac : seg[idx];
+    }
+    if ((int)sid < n_series_segments) {
+        const int age = (int)(sid % a.n);
+        const int t = (int)((sid / a.n) % a.Tp);
+        const int ser = (int)(sid / ((size_t)a.n * a.Tp));
+        a.q_out[(((size_t)ser * a.n_probs + p) * a.Tp + t) * a.n + age] = r;
+    } else if (a.rt_out != nullptr && (int)sid >= a.rt_segment0) {
+        a.rt_out[(size_t)p * a.T + (sid - (size_t)a.rt_segment0)] = r;
+    } else {
+        const size_t k = sid - (size_t)n_series_segments;
+        a.sero_out[(size_t)p * a.T + k] = r;
+    }
+}
+
 // Pass 2: one workgroup per segment; bitonic sort in LDS, then the interpolated quantiles.
 __global__ void ensemble_quantile_kernel(const EnsembleArgs a, const int n_series_segments) {
     extern __shared__ double seg[];
@@ -342,34 +370,25 @@ __global__ void ensemble_quantile_kernel(const EnsembleArgs a, const int n_serie
         }
     }
     const int nv = *a.n_valid;
-    for (int p = tid; p < a.n_probs; p += BS) {
-        double r = NAN;
-        if (nv > 0) {
-            const double pos = a.probs[p] * (double)(size_t)(nv - 1);
-            const size_t idx = (size_t)pos;
-            const double frac = pos - (double)idx;
-            r = (idx + 1 < (size_t)nv) ? seg[idx] * (1.0 - frac) + seg[idx + 1] * frac : seg[idx];
-        }
-        if ((int)sid < n_series_segments) {
-            const int age = (int)(sid % a.n);
-            const int t = (int)((sid / a.n) % a.Tp);
-            const int ser = (int)(sid / ((size_t)a.n * a.Tp));
-            a.q_out[(((size_t)ser * a.n_probs + p) * a.Tp + t) * a.n + age] = r;
-        } else if (a.rt_out != nullptr && (int)sid >= a.rt_segment0) {
-            a.rt_out[(size_t)p * a.T + (sid - (size_t)a.rt_segment0)] = r;
-        } else {
-            const size_t k = sid - (size_t)n_series_segments;
-            a.sero_out[(size_t)p * a.T + k] = r;
-        }
-    }
+    for (int p = tid; p < a.n_probs; p += BS) write_quantile(a, n_series_segments, sid, p, nv, seg);
+}
+
+// Large ensembles (more samples than fit LDS): the segments of a group were sorted in global memory by the
+// library's segmented radix sort; one thread per (segment, probability) interpolates.
+__global__ void ensemble_quantile_sorted_kernel(const EnsembleArgs a, const int n_series_segments, const double* sorted,
+                                                const int first_segment, const int n_group) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_group * a.n_probs) return;
+    const int g = (int)(idx / a.n_probs), p = (int)(idx % a.n_probs);
+    write_quantile(a, n_series_segments, (size_t)(first_segment + g), p, *a.n_valid, sorted + (size_t)g * a.S_pad);
 }
 
 }  // namespace
 
 int launch_ensemble_summaries(const EnsembleArgs& a, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (a.S <= 0 || a.S_pad < WAVE || (a.S_pad & (a.S_pad - 1)) != 0 || a.S_pad > ENSEMBLE_MAX_SAMPLES || a.S > a.S_pad)
-        return -4;
+    const bool in_lds = a.S_pad <= ENSEMBLE_MAX_SAMPLES;
+    if (a.S <= 0 || a.S_pad < WAVE || a.S > a.S_pad || (in_lds ? (a.S_pad & (a.S_pad - 1)) != 0 : a.S_pad % WAVE != 0)) return -4;
     hipLaunchKernelGGL(ensemble_count_valid_kernel, dim3(1), dim3(256), 0, st, a.wstatus, a.S, a.n_valid);
     const size_t cols = (size_t)a.S_pad * a.lpc;
     hipLaunchKernelGGL(ensemble_series_kernel, dim3((unsigned)((cols + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a);
@@ -386,6 +405,44 @@ int launch_ensemble_summaries(const EnsembleArgs& a, void* stream) {
         hipLaunchKernelGGL(ensemble_metrics_kernel, dim3((unsigned)((a.S + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, a, *a.pb, a.theta);
     }
     const int segments = n_series_segments + (sero ? a.T : 0) + (rt ? a.T : 0);
+    if (!in_lds) {
+        // segments of S_pad doubles sorted in groups by rocPRIM's segmented radix sort (8 passes over the keys)
+        // into a scratch buffer, quantiles picked from it; group size bounded by the scratch buffer
+        int group = (int)(a.sort_scratch_doubles / (size_t)a.S_pad);
+        if (group > segments) group = segments;
+        if (group < 1 || (size_t)group * a.S_pad >= (size_t)1 << 31) return -4;
+        std::vector<unsigned> offs((size_t)group + 1);
+        for (int g = 0; g <= group; ++g) offs[(size_t)g] = (unsigned)((size_t)g * a.S_pad);
+        unsigned* d_offs = nullptr;
+        if (hipMalloc((void**)&d_offs, offs.size() * sizeof(unsigned)) != hipSuccess) return -3;
+        int rc = 0;
+        if (hipMemcpyAsync(d_offs, offs.data(), offs.size() * sizeof(unsigned), hipMemcpyHostToDevice, st) != hipSuccess) rc = -3;
+        void* tmp = nullptr;
+        size_t tmp_bytes = 0;
+        for (int first = 0; first < segments && rc == 0; first += group) {
+            const int ng = (segments - first < group) ? segments - first : group;
+            const double* in = a.vals + (size_t)first * a.S_pad;
+            const unsigned size = (unsigned)((size_t)ng * a.S_pad);
+            size_t need = 0;
+            if (rocprim::segmented_radix_sort_keys(nullptr, need, in, a.sort_scratch, size, (unsigned)ng, d_offs, d_offs + 1, 0, 64,
+                                                   st) != hipSuccess) { rc = -3; break; }
+            if (need > tmp_bytes) {
+                if (tmp) (void)hipFree(tmp);
+                tmp = nullptr;
+                if (hipMalloc(&tmp, need) != hipSuccess) { rc = -3; break; }
+                tmp_bytes = need;
+            }
+            if (rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, in, a.sort_scratch, size, (unsigned)ng, d_offs, d_offs + 1, 0, 64,
+                                                   st) != hipSuccess) { rc = -3; break; }
+            const size_t work = (size_t)ng * a.n_probs;
+            hipLaunchKernelGGL(ensemble_quantile_sorted_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a,
+                               n_series_segments, a.sort_scratch, first, ng);
+        }
+        (void)hipStreamSynchronize(st);
+        if (tmp) (void)hipFree(tmp);
+        (void)hipFree(d_offs);
+        return (rc == 0 && hipGetLastError() == hipSuccess) ? 0 : -3;
+    }
     const int threads = a.S_pad / 2 < 1024 ? a.S_pad / 2 : 1024;
     const size_t lds = (size_t)a.S_pad * sizeof(double);
     if (lds > 48 * 1024 &&

@@ -224,3 +224,22 @@ def test_hip_essential_metrics_table(mm, oracle_py, shipped):
     assert np.all(ref[:, 0] > 1.0) and np.all((ref[:, 11] > 0) & (ref[:, 11] < 0.2))  # R0 > 1, plausible seroprevalence
     only = hip.ensemble_quantiles(theta, PROBS, want_sero=False, want_rt=False, want_metrics=True)["metrics"]
     assert np.array_equal(only, got)
+
+
+@pytest.mark.gpu
+def test_hip_ensemble_larger_than_the_lds_sort(mm, oracle_py, ref_fixture):
+    """More than 16 384 samples: segments are sorted in global memory (library segmented radix sort) instead of
+    LDS; same quantile rule, same numbers as the oracle."""
+    pb = ref_fixture.with_(arith=mm.ARITH_STRICT)
+    S = 16384 + 3000 + 7   # not a multiple of 64
+    base = _draws(oracle_py, pb, 4096, seed0=5)
+    theta = np.tile(base, (S // 4096 + 1, 1))[:S]
+    theta[:, 0] *= 1.0 + 1e-3 * np.arange(S) / S   # make the tiled samples distinct
+    ref = oracle_py.Oracle(pb).ensemble_quantiles(theta, PROBS)
+    hip = mm.HipObjective(pb)
+    hip.set_initial_state_mode(1)
+    got = hip.ensemble_quantiles(theta, PROBS, want_sero=True, want_rt=True)
+    assert got["n_valid"] == ref["n_valid"] == S
+    np.testing.assert_allclose(got["ppc"], ref["ppc"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(got["sero"], ref["sero"], rtol=1e-9, atol=1e-12)
+    assert np.all(np.diff(got["rt"], axis=0) >= 0)
