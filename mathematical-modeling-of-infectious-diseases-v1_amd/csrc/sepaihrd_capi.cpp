@@ -30,6 +30,10 @@ struct sepaihrd_ctx {
     std::vector<uint8_t> has_bounds;
     int n = 0, T = 0, P = 0;
     std::vector<double> host_N;  // population sizes (ensemble seroprevalence)
+    // buffers of sepaihrd_ensemble_quantiles, kept between calls (grow-only): allocating tens of GB per call
+    // costs more than the kernels at large ensembles
+    void* ens_buf[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ens_cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::string last_error;
     // staging buffers for the host-pointer entry point (grown on demand)
     size_t cap_B = 0;
@@ -368,6 +372,8 @@ void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     free_staging(ctx);
     free_workspace(ctx);
+    for (void* p : ctx->ens_buf)
+        if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
@@ -581,11 +587,19 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
     const size_t n_scratch = big ? std::max<size_t>((size_t)S_pad, std::min<size_t>(n_vals, (size_t)1 << 28) / S_pad * S_pad) : 0;
     const size_t n_metrics = want_metrics ? (size_t)S * (12 + 4 * dp.n) : 0;
     int32_t* d_nv = nullptr;
-    std::vector<void*> tmp;
-    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() {};  // the buffers stay with the context
+    int slot = 0;
     auto dalloc = [&](void** p, size_t bytes) {
-        if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) return false;
-        tmp.push_back(*p);
+        const int k = slot++;
+        if (bytes == 0) bytes = 8;
+        if (ctx->ens_cap[k] < bytes) {
+            if (ctx->ens_buf[k]) (void)hipFree(ctx->ens_buf[k]);
+            ctx->ens_buf[k] = nullptr;
+            ctx->ens_cap[k] = 0;
+            if (hipMalloc(&ctx->ens_buf[k], bytes) != hipSuccess) return false;
+            ctx->ens_cap[k] = bytes;
+        }
+        *p = ctx->ens_buf[k];
         return true;
     };
     if (!dalloc((void**)&d_theta, (size_t)S * ctx->P * sizeof(double)) || !dalloc((void**)&d_ll, (size_t)S * sizeof(double)) ||
