@@ -275,3 +275,22 @@ def test_device_entry_point_is_graph_capturable(mm, synth400, draws):
     graph.replay()
     torch.cuda.synchronize()
     assert np.array_equal(d_ll.cpu().numpy(), want_b)
+
+
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_shortest_grids(mm, oracle_py, ref_fixture, T, solver):
+    """One, two and three output times (the observer fires once at t0; one interval = the first attempt is one
+    step of the whole interval): same status, counters, states and likelihood as the oracle."""
+    times = np.array([0.0, 0.37, 1.0])[:T]
+    pb = ref_fixture.with_(times=times, solver=solver, arith=mm.ARITH_STRICT, obs_H=ref_fixture.obs_H[:T],
+                           obs_ICU=ref_fixture.obs_ICU[:T], obs_D=ref_fixture.obs_D[:T])
+    rs = np.random.RandomState(T)
+    lo, hi, _ = pb.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(0, 1, (9, pb.n_params))
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"])
+    assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-12
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
