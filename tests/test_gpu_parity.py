@@ -294,3 +294,18 @@ def test_shortest_grids(mm, oracle_py, ref_fixture, T, solver):
     assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
     assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-12
     np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+
+
+def test_minimal_problem_one_parameter_no_schedule(mm, oracle_py, ref_fixture):
+    """One calibrated parameter, a single kappa period (no breakpoint inside the run), one age class."""
+    pb = mm.restrict_age_classes(ref_fixture, [1])
+    pb = pb.with_(param_names=["beta"], sigmas={"beta": 0.01}, bounds={"beta": (0.01, 1.0)}, base_theta=np.array([0.06]),
+                  kappa_end_times=np.array([1000.0]), kappa_values=np.array([0.8]), npi_names=[], arith=mm.ARITH_STRICT)
+    theta = np.linspace(0.02, 0.4, 23)[:, None]
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"]) and np.all(ref["status"] == 0)
+    assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+    assert np.ptp(got["loglik"]) > 0  # the one parameter matters
