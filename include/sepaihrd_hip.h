@@ -264,7 +264,7 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, c
  *             adaptation-period step (:283-301): full two-pass recompute when recompute_full != 0
  *             (caller checks history >= P + 10), then the Cholesky factor of cov + eps I, kept on success
  *   read_history / read_covariance   rows of the history [C][n_rows][P], covariances [C][P][P]
- * P <= 128.  A sampler object borrows its context: destroy it before the context, and use one sampler per
+ * P <= 200 (the factorisation keeps a packed lower triangle in LDS).  A sampler object borrows its context: destroy it before the context, and use one sampler per
  * context at a time (it evaluates through the context's workspace on its own stream). */
 typedef struct sepaihrd_mh sepaihrd_mh;
 sepaihrd_mh *sepaihrd_mh_create(sepaihrd_ctx *ctx, int C, int capacity, const double *x0, const double *cov0,

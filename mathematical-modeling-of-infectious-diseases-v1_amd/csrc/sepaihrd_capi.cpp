@@ -744,8 +744,8 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
                                 double reg_eps, double scaling_factor) {
     if (!ctx) return nullptr;
     const int P = ctx->P;
-    if (C <= 0 || capacity <= 0 || !x0 || !cov0 || P > 128) {
-        ctx->last_error = "mh_create: need C > 0, capacity > 0, x0, cov0 and at most 128 parameters";
+    if (C <= 0 || capacity <= 0 || !x0 || !cov0 || P > 200) {
+        ctx->last_error = "mh_create: need C > 0, capacity > 0, x0, cov0 and at most 200 parameters";
         return nullptr;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->last_error = "hipSetDevice failed"; return nullptr; }

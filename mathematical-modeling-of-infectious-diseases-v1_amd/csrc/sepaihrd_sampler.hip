@@ -140,35 +140,39 @@ __global__ __launch_bounds__(WAVE) void mh_full_cov_kernel(const SamplerState s,
 }
 
 // Lower Cholesky factor of cov (+ diag_add on the diagonal), one workgroup per chain, factor built in
-// LDS.  on_failure: 0 = leave chol untouched ("kept only on success"), 1 = 0.1 I (:242-244).
+// LDS (packed lower triangle: P <= 200 in 160 KiB).  on_failure: 0 = leave chol untouched ("kept only on success"), 1 = 0.1 I (:242-244).
 __global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s, const double diag_add, const int on_failure) {
-    extern __shared__ double L[];  // P x P row-major
+    extern __shared__ double L[];  // lower triangle packed row by row: (i, j) at i (i + 1) / 2 + j, j <= i
     __shared__ int ok;
     const int c = blockIdx.x, P = s.P, tid = threadIdx.x;
     const double* A = s.cov + (size_t)c * P * P;
-    for (int e = tid; e < P * P; e += WAVE) L[e] = 0.0;
     if (tid == 0) ok = 1;
     __syncthreads();
     for (int j = 0; j < P; ++j) {
+        const int rj = j * (j + 1) / 2;
         if (tid == (j % WAVE)) {
             double d = A[(size_t)j * P + j] + diag_add;
-            for (int k = 0; k < j; ++k) d -= L[j * P + k] * L[j * P + k];
+            for (int k = 0; k < j; ++k) d -= L[rj + k] * L[rj + k];
             if (!(d > 0.0)) ok = 0;
-            else L[j * P + j] = sqrt(d);
+            else L[rj + j] = sqrt(d);
         }
         __syncthreads();
         if (!ok) break;
-        const double ljj = L[j * P + j];
+        const double ljj = L[rj + j];
         for (int i = j + 1 + tid; i < P; i += WAVE) {
+            const int ri = i * (i + 1) / 2;
             double v = A[(size_t)i * P + j];
-            for (int k = 0; k < j; ++k) v -= L[i * P + k] * L[j * P + k];
-            L[i * P + j] = v / ljj;
+            for (int k = 0; k < j; ++k) v -= L[ri + k] * L[rj + k];
+            L[ri + j] = v / ljj;
         }
         __syncthreads();
     }
     double* dst = s.chol + (size_t)c * P * P;
     if (ok) {
-        for (int e = tid; e < P * P; e += WAVE) dst[e] = L[e];
+        for (int e = tid; e < P * P; e += WAVE) {
+            const int i = e / P, j = e % P;
+            dst[e] = (j <= i) ? L[i * (i + 1) / 2 + j] : 0.0;
+        }
     } else if (on_failure == 1) {
         for (int e = tid; e < P * P; e += WAVE) dst[e] = (e / P == e % P) ? 0.1 : 0.0;
     }
@@ -204,7 +208,7 @@ int sampler_full_covariance(const SamplerState& s, int len, void* stream) {
 }
 
 int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream) {
-    const size_t lds = (size_t)s.P * s.P * sizeof(double);
+    const size_t lds = (size_t)s.P * (s.P + 1) / 2 * sizeof(double);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&mh_cholesky_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)

@@ -206,3 +206,20 @@ def test_chain_groups_on_separate_streams_give_the_single_group_result(mm, oracl
     grp = mm.hostabi.metropolis_hastings_groups(objs, x0, **kw)
     for k in ("accept_trace", "accepted", "best_value", "best"):
         assert np.array_equal(grp[k], one[k]), k
+
+
+def test_device_resident_sampler_with_158_parameters(mm, oracle_py, shipped):
+    """BASELINE config 5's shape (16 age groups, 158 calibrated parameters): the factorisation keeps a packed
+    lower triangle in LDS; device-resident state == host loop."""
+    pb = mm.widen_age_classes(shipped, 4)
+    pb.arith = mm.ARITH_STRICT
+    pb.constraint_mode = 1
+    pb.times = pb.times[:60]
+    pb = pb.with_(obs_H=pb.obs_H[:40], obs_ICU=pb.obs_ICU[:40], obs_D=pb.obs_D[:40])
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 3, 3)
+    kw = dict(seed=29, iterations=230, burn_in=20, adaptation_period=30, thinning=10)  # refreshes from t = 180 (>= P + 10 rows)
+    host = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best", "samples", "sample_values", "final_scale"):
+        assert np.array_equal(dev[k], host[k]), k
