@@ -46,3 +46,18 @@ def test_end_to_end_calibration_driver(tmp_path):
     rt = list(csv.reader(open(out / "Rt_aggregated_with_uncertainty.csv")))
     assert len(rt) == 1 + 326 and float(rt[1][3]) > 1.0 > float(rt[-1][3]) * 0.5
     assert len(list(csv.reader(open(out / "essential_metrics.csv")))) == 1 + summary["ensemble_samples"]
+
+
+C_SMOKE = os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke")
+
+
+def test_header_is_valid_c99_and_links():
+    """tests/c_abi/c_abi_smoke.c compiles with gcc -std=c99 -Wall -Wextra -Werror against include/sepaihrd_hip.h
+    (done by __graft_entry__.build())."""
+    assert os.path.exists(C_SMOKE), "run __graft_entry__.build() (make -C tests/c_abi)"
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_of_the_abi():
+    r = subprocess.run([C_SMOKE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK", r.stdout + r.stderr
