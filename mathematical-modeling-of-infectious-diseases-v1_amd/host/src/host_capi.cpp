@@ -4,6 +4,7 @@
 #include <sstream>
 
 #include "epidemic_hip/BatchedHillClimbing.hpp"
+#include "epidemic_hip/BatchedParticleSwarm.hpp"
 #include "epidemic_hip/HipModelCalibrator.hpp"
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
@@ -301,6 +302,33 @@ int host_hc_run(void* hv, const double* x0, uint32_t seed, int threads, int iter
         if (trace) std::copy(hc.currentTrace().begin(), hc.currentTrace().end(), trace);
         if (evaluations) *evaluations = hc.evaluations();
         if (launches) *launches = hc.launches();
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// BatchedParticleSwarmOptimization.  settings: n_settings (key, value) pairs, keys as in pso_settings.txt plus `seed`.
+int host_pso_run(void* hv, const double* x0, const char* const* keys, const double* values, int n_settings,
+                 double* best, double* best_value, double* final_cov, double* trace, long* evaluations, long* launches) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        h->pm->setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);
+        std::map<std::string, double> settings;
+        for (int i = 0; i < n_settings; ++i) settings[keys[i]] = values[i];
+        BatchedParticleSwarmOptimization pso;
+        pso.configure(settings);
+        const OptimizationResult r = pso.optimize(x0 ? vec(x0, P) : Eigen::VectorXd(), *h->obj, *h->pm);
+        for (int i = 0; i < P; ++i) best[i] = r.bestParameters[i];
+        *best_value = r.bestObjectiveValue;
+        if (final_cov)
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b) final_cov[static_cast<size_t>(a) * P + b] = r.finalCovariance(a, b);
+        if (trace) std::copy(pso.bestTrace().begin(), pso.bestTrace().end(), trace);
+        if (evaluations) *evaluations = pso.evaluations();
+        if (launches) *launches = pso.launches();
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

@@ -44,6 +44,7 @@ def load_library() -> C.CDLL:
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.host_pso_run.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
                                   vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     _lib = lib
@@ -88,6 +89,28 @@ class HostObjective:
                                   trace.ctypes.data, C.byref(ne), C.byref(nl))
         if rc != 0:
             raise RuntimeError("host_hc_run: " + self.lib.host_last_error().decode())
+        return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace,
+                "evaluations": ne.value, "launches": nl.value}
+
+    def particle_swarm(self, x0, seed: int, **settings) -> dict:
+        """BatchedParticleSwarmOptimization::optimize in OPTIMIZATION_CLAMP mode; settings as in pso_settings.txt."""
+        settings = dict(settings, seed=seed)
+        keys = (C.c_char_p * len(settings))(*[k.encode() for k in settings])
+        vals = np.array([float(v) for v in settings.values()])
+        x0p = None
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            x0p = x0.ctypes.data
+        iters = int(settings.get("iterations", 100))
+        best = np.empty(self.P)
+        cov = np.empty((self.P, self.P))
+        trace = np.empty(iters)
+        bv = C.c_double(0.0)
+        ne, nl = C.c_long(0), C.c_long(0)
+        rc = self.lib.host_pso_run(self.h, x0p, keys, vals.ctypes.data, len(settings), best.ctypes.data, C.byref(bv),
+                                   cov.ctypes.data, trace.ctypes.data, C.byref(ne), C.byref(nl))
+        if rc != 0:
+            raise RuntimeError("host_pso_run: " + self.lib.host_last_error().decode())
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace,
                 "evaluations": ne.value, "launches": nl.value}
 

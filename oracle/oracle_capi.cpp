@@ -249,6 +249,42 @@ int oracle_hc(void* hv, int iterations, int cloud_size_multiplier, int threads, 
     return 0;
 }
 
+// cfg: [iterations, swarm_size, max_stagnation, omega_start, omega_end, c1_initial, c1_final, c2_initial, c2_final,
+//       variant, topology, use_opposition_learning, use_adaptive_parameters, restart_threshold, quantum_beta,
+//       levy_alpha, deferred_personal_bests]
+int oracle_pso(void* hv, const double* cfg_values, const double* x0, uint32_t seed, double* best, double* best_value,
+               double* final_cov, double* trace, long* evaluations) {
+    auto* h = static_cast<Handle*>(hv);
+    const int P = static_cast<int>(h->pb.pm.names.size());
+    oracle::PSOSettings cfg;
+    const double* c = cfg_values;
+    cfg.iterations = int(c[0]); cfg.swarm_size = int(c[1]); cfg.max_stagnation = int(c[2]);
+    cfg.omega_start = c[3]; cfg.omega_end = c[4]; cfg.c1_initial = c[5]; cfg.c1_final = c[6];
+    cfg.c2_initial = c[7]; cfg.c2_final = c[8]; cfg.variant = int(c[9]); cfg.topology = int(c[10]);
+    cfg.use_opposition_learning = c[11] != 0.0; cfg.use_adaptive_parameters = c[12] != 0.0;
+    cfg.restart_threshold = c[13]; cfg.quantum_beta = c[14]; cfg.levy_alpha = c[15];
+    cfg.deferred_personal_bests = c[16] != 0.0;
+    oracle::Problem pb = h->pb;
+    pb.pm.mode = oracle::OPTIMIZATION_CLAMP;
+    auto fn = [&](const std::vector<double>& p) {
+        oracle::EvalInfo info;
+        const double v = oracle::objective(pb, p, &info);
+        if (info.status >= 2) throw std::runtime_error("SimulationException");
+        return v;
+    };
+    std::vector<double> start;
+    if (x0) start.assign(x0, x0 + P);
+    try {
+        const oracle::PSOResult r = oracle::particle_swarm(cfg, x0 ? &start : nullptr, fn, pb.pm, seed);
+        std::copy(r.best.begin(), r.best.end(), best);
+        *best_value = r.best_value;
+        if (final_cov) std::copy(r.final_cov.begin(), r.final_cov.end(), final_cov);
+        if (trace) std::copy(r.best_trace.begin(), r.best_trace.end(), trace);
+        if (evaluations) *evaluations = r.evaluations;
+    } catch (const std::exception&) { return 2; }
+    return 0;
+}
+
 int oracle_gradient(void* hv, const double* theta, double epsilon, double* value, double* grad) {
     auto* h = static_cast<Handle*>(hv);
     const int P = static_cast<int>(h->pb.pm.names.size());

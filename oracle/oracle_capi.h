@@ -57,6 +57,10 @@ int oracle_ensemble(void *h, const double *theta, int S, const double *probs, in
 /* HillClimbingOptimizer restated (seeded, virtual threads).  trace: [iterations] current logL. */
 int oracle_hc(void *h, int iterations, int cloud_size_multiplier, int threads, const double *x0, uint32_t seed,
               double *best, double *best_value, double *final_cov, double *trace, long *evaluations);
+/* ParticleSwarmOptimization restated (seeded; one evaluation at a time).  cfg: 17 doubles, order in oracle_capi.cpp.
+ * x0 nullable (no warm-start particle).  trace: [iterations] global best.  Returns 2 when an integration throws. */
+int oracle_pso(void *h, const double *cfg, const double *x0, uint32_t seed, double *best, double *best_value,
+               double *final_cov, double *trace, long *evaluations);
 /* SEPAIHRDGradientObjectiveFunction::evaluate_with_gradient restated; returns 0, or 2 when an integration throws */
 int oracle_gradient(void *h, const double *theta, double epsilon, double *value, double *grad);
 /* ModelCalibrator restated: HC phase (clamp) -> covariance conditioning -> one MH chain (reflect).

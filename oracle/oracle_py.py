@@ -70,6 +70,7 @@ def load(path: str | None = None) -> C.CDLL:
                               C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.oracle_pso.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.oracle_gradient.argtypes = [vp, vp, C.c_double, vp, vp]
     lib.oracle_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -188,6 +189,35 @@ class Oracle:
         ne = C.c_long(0)
         self.lib.oracle_hc(self.h, iterations, cloud_size_multiplier, threads, x0.ctypes.data, seed, best.ctypes.data,
                            C.byref(bv), cov.ctypes.data, trace.ctypes.data, C.byref(ne))
+        return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace, "evaluations": ne.value}
+
+    PSO_KEYS = ("iterations", "swarm_size", "max_stagnation", "omega_start", "omega_end", "c1_initial", "c1_final",
+                "c2_initial", "c2_final", "variant", "topology", "use_opposition_learning", "use_adaptive_parameters",
+                "restart_threshold", "quantum_beta", "levy_alpha", "deferred_personal_bests")
+    PSO_DEFAULTS = (100, 30, 50, 0.9, 0.4, 2.5, 0.5, 0.5, 2.5, 0, 0, 0, 0, 1e-6, 1.0, 1.5, 0)
+
+    def particle_swarm(self, x0, seed: int, **settings) -> dict:
+        """ParticleSwarmOptimization restated; settings as in pso_settings.txt (+ deferred_personal_bests)."""
+        cfg = dict(zip(self.PSO_KEYS, self.PSO_DEFAULTS))
+        unknown = set(settings) - set(cfg)
+        if unknown:
+            raise KeyError(f"unknown PSO settings: {sorted(unknown)}")
+        cfg.update(settings)
+        vals = np.array([float(cfg[k]) for k in self.PSO_KEYS])
+        x0p = None
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            x0p = x0.ctypes.data
+        iters = int(cfg["iterations"])
+        best = np.empty(self.P)
+        cov = np.empty((self.P, self.P))
+        trace = np.empty(iters)
+        bv = C.c_double(0.0)
+        ne = C.c_long(0)
+        rc = self.lib.oracle_pso(self.h, vals.ctypes.data, x0p, seed, best.ctypes.data, C.byref(bv), cov.ctypes.data,
+                                 trace.ctypes.data, C.byref(ne))
+        if rc != 0:
+            raise RuntimeError("SimulationException")
         return {"best": best, "best_value": bv.value, "final_cov": cov, "trace": trace, "evaluations": ne.value}
 
     def evaluate_with_gradient(self, theta, epsilon: float = 1e-4):

@@ -1501,6 +1501,315 @@ inline CalibrationResult calibrate(const HCSettings& hc_cfg, MHSettings mh_cfg, 
 }
 
 // -----------------------------------------------------------------------------
+// ParticleSwarmOptimization (src/model/optimizers/ParticleSwarmOptimizer.cpp:105-948) restated as the reference
+// runs it with use_parallel = 0: ONE particle at a time -- draw its neighbourhood best, move it, evaluate it,
+// update its personal best -- so that a later particle of the same iteration already sees the earlier ones'
+// new personal bests (:377-432).  `deferred_personal_bests` holds those updates back until the iteration's loop
+// has finished, which is the outcome the reference's `omp parallel for` aims at and the order the batched
+// product path (one launch per iteration) necessarily has; with the GLOBAL_BEST topology no particle reads
+// another's personal best inside the loop and the two orders coincide.
+// The reference seeds `rng_` from std::random_device (ParticleSwarmOptimizer.hpp:228); here it takes a seed.
+// One deviation, marked below: the HYBRID variant's quantum branch receives the mean personal best (the
+// reference passes an empty vector there, :356-359 with :407-409, and indexes it).
+// -----------------------------------------------------------------------------
+struct PSOSettings {
+    int iterations = 100, swarm_size = 30, max_stagnation = 50;
+    double omega_start = 0.9, omega_end = 0.4, c1_initial = 2.5, c1_final = 0.5, c2_initial = 0.5, c2_final = 2.5;
+    int variant = 0;   // 0 standard, 1 quantum, 2 adaptive, 3 Levy flight, 4 hybrid
+    int topology = 0;  // 0 global best, 1 ring (k = 2), 2 von Neumann grid, 3 random dynamic
+    bool use_opposition_learning = false, use_adaptive_parameters = false;
+    double restart_threshold = 1e-6, quantum_beta = 1.0, levy_alpha = 1.5;
+    bool deferred_personal_bests = false;
+};
+
+struct PSOResult {
+    std::vector<double> best;
+    double best_value = 0.0;
+    std::vector<double> final_cov;   // P x P row-major
+    std::vector<double> best_trace;  // global best after every iteration
+    long evaluations = 0;
+};
+
+inline PSOResult particle_swarm(const PSOSettings& cfg, const std::vector<double>* x0, const Objective& objective_fn,
+                                const ParameterManager& pm, uint32_t seed) {
+    const int P = static_cast<int>(pm.names.size());
+    const int S = cfg.swarm_size;
+    PSOResult r;
+    struct Ptl {  // ParticleSwarmOptimizer.hpp `particle`
+        std::vector<double> x, v, pb_x, q_x;
+        double pb = -std::numeric_limits<double>::infinity(), fit = -std::numeric_limits<double>::infinity(), rate = 0.0;
+        int wins = 0, moves = 0;
+    };
+    std::vector<double> lb(P), ub(P);
+    for (int k = 0; k < P; ++k) {
+        const auto& bd = pm.bounds.at(pm.names[k]);  // getLower/UpperBoundForParamIndex throw without bounds
+        lb[k] = bd.first;
+        ub[k] = bd.second;
+    }
+    auto f = [&](const std::vector<double>& p) { ++r.evaluations; return objective_fn(p); };
+    auto clip = [](double v, double lo, double hi) { return v < lo ? lo : (hi < v ? hi : v); };  // std::clamp
+    std::mt19937 master(seed);
+    std::uniform_real_distribution<> master_u(0.0, 1.0);  // uniform_dist_ / normal_dist_: members, state persists
+    std::normal_distribution<> master_n(0.0, 1.0);
+    std::vector<Ptl> sw(S);
+    std::vector<double> g_x(P, 0.0);
+    double g = -std::numeric_limits<double>::infinity();
+    int stagnation = 0;
+    auto draw_seeds = [&]() {
+        std::vector<unsigned int> sd(S);
+        for (int i = 0; i < S; ++i) sd[i] = static_cast<unsigned int>(master());
+        return sd;
+    };
+
+    // ---- initializeSwarm :249-328
+    {
+        const std::vector<unsigned int> sd = draw_seeds();
+        for (int i = 0; i < S; ++i) {
+            Ptl& p = sw[i];
+            p.x.resize(P); p.v.resize(P);
+            std::mt19937 lr(sd[i]);
+            std::uniform_real_distribution<> lu(0.0, 1.0);
+            for (int k = 0; k < P; ++k)
+                p.x[k] = (i == 0 && x0) ? clip((*x0)[k], lb[k], ub[k]) : lb[k] + lu(lr) * (ub[k] - lb[k]);
+            for (int k = 0; k < P; ++k) {
+                const double vmax = 0.2 * (ub[k] - lb[k]);
+                p.v[k] = -vmax + 2 * vmax * lu(lr);
+            }
+            p.fit = f(p.x);
+            p.pb_x = p.x; p.pb = p.fit; p.q_x = p.x;
+        }
+        if (cfg.use_opposition_learning) {  // :527-574 then :309-314
+            std::vector<Ptl> mirror(S);
+            for (int i = 0; i < S; ++i) {
+                mirror[i].x.resize(P); mirror[i].v.resize(P);
+                for (int k = 0; k < P; ++k) {
+                    mirror[i].x[k] = lb[k] + ub[k] - sw[i].x[k];
+                    mirror[i].v[k] = -sw[i].v[k];
+                }
+                mirror[i].q_x = mirror[i].x; mirror[i].pb_x = mirror[i].x;  // pb stays -inf: never evaluated
+            }
+            std::vector<std::pair<double, int>> order;
+            for (int i = 0; i < S; ++i) { order.push_back({sw[i].pb, i}); order.push_back({mirror[i].pb, i + S}); }
+            std::sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            std::vector<Ptl> chosen(S);
+            for (int i = 0; i < S; ++i) chosen[i] = order[i].second < S ? sw[order[i].second] : mirror[order[i].second - S];
+            sw = std::move(chosen);
+            for (int i = 0; i < S; ++i) { sw[i].fit = f(sw[i].x); sw[i].pb = sw[i].fit; sw[i].pb_x = sw[i].x; }
+        }
+        for (const Ptl& p : sw) if (p.pb > g) { g = p.pb; g_x = p.pb_x; }
+    }
+
+    auto neighbours = [&](int i) {  // getNeighbors :836-906
+        std::vector<int> nb;
+        if (cfg.topology == 0) { for (int j = 0; j < S; ++j) nb.push_back(j); }
+        else if (cfg.topology == 1) {
+            nb.push_back(i);
+            for (int j = 1; j <= 2; ++j) { nb.push_back((i - j + S) % S); nb.push_back((i + j) % S); }
+        } else if (cfg.topology == 2) {
+            const int gs = static_cast<int>(std::ceil(std::sqrt(S)));
+            const int row = i / gs, col = i % gs;
+            nb.push_back(i);
+            if (row > 0 && (row - 1) * gs + col < S) nb.push_back((row - 1) * gs + col);
+            if (row < gs - 1 && (row + 1) * gs + col < S) nb.push_back((row + 1) * gs + col);
+            if (col > 0 && row * gs + col - 1 < S) nb.push_back(row * gs + col - 1);
+            if (col < gs - 1 && row * gs + col + 1 < S) nb.push_back(row * gs + col + 1);
+        } else {
+            nb.push_back(i);
+            std::vector<int> cand;
+            for (int j = 0; j < S; ++j) if (j != i) cand.push_back(j);
+            std::shuffle(cand.begin(), cand.end(), master);
+            nb.insert(nb.end(), cand.begin(), cand.begin() + std::min(4, static_cast<int>(cand.size())));
+        }
+        return nb;
+    };
+    auto neighbourhood_best = [&](int i) {  // :816-834
+        std::vector<double> bx = sw[i].pb_x;
+        double bv = sw[i].pb;
+        for (int j : neighbours(i))
+            if (j >= 0 && j < S && sw[j].pb > bv) { bv = sw[j].pb; bx = sw[j].pb_x; }
+        return bx;
+    };
+    auto move_standard = [&](Ptl& p, const std::vector<double>& lbest, double omega, double c1, double c2,
+                             std::mt19937& lr) {  // :576-618
+        std::uniform_real_distribution<> lu(0.0, 1.0);
+        std::vector<double> r1(P), r2(P);
+        for (int k = 0; k < P; ++k) { r1[k] = lu(lr); r2[k] = lu(lr); }
+        for (int k = 0; k < P; ++k) {
+            const double cognitive = c1 * (r1[k] * (p.pb_x[k] - p.x[k]));
+            const double social = c2 * (r2[k] * (lbest[k] - p.x[k]));
+            double v = omega * p.v[k] + cognitive + social;
+            const double vmax = 0.2 * (ub[k] - lb[k]);
+            v = clip(v, -vmax, vmax);
+            double x = p.x[k] + v;
+            if (x < lb[k]) { x = lb[k] + std::abs(x - lb[k]); v *= -0.5; }
+            else if (x > ub[k]) { x = ub[k] - std::abs(x - ub[k]); v *= -0.5; }
+            p.x[k] = clip(x, lb[k], ub[k]);
+            p.v[k] = v;
+        }
+    };
+    auto move_quantum = [&](Ptl& p, const std::vector<double>& mbest, int iter, std::mt19937& lr) {  // :620-653
+        std::uniform_real_distribution<> lu(0.0, 1.0);
+        const double phi = lu(lr);
+        const double beta = cfg.quantum_beta * (1.0 - 0.5 * static_cast<double>(iter) / cfg.iterations);
+        for (int k = 0; k < P; ++k) {
+            const double attractor = phi * p.pb_x[k] + (1 - phi) * g_x[k];
+            const double u = lu(lr);
+            const double L = 2.0 * beta * std::abs(mbest[k] - p.x[k]);
+            const double side = lu(lr);
+            p.x[k] = clip(side < 0.5 ? attractor + L * std::log(1.0 / u) : attractor - L * std::log(1.0 / u), lb[k], ub[k]);
+        }
+        p.q_x = p.x;
+    };
+    auto move_levy = [&](Ptl& p, double omega, double c1, double c2, std::mt19937& lr) {  // :655-680, :908-934
+        move_standard(p, g_x, omega, c1, c2, lr);
+        std::uniform_real_distribution<> lu(0.0, 1.0);
+        if (lu(lr) < 0.1 * (1.0 + p.rate)) {
+            const double a = cfg.levy_alpha;
+            std::vector<double> step(P);
+            for (int k = 0; k < P; ++k) {  // Mantegna; a fresh normal_distribution per number
+                const double sigma_u = std::pow(std::tgamma(1 + a) * std::sin(M_PI * a / 2) /
+                                                    (std::tgamma((1 + a) / 2) * a * std::pow(2, (a - 1) / 2)),
+                                                1.0 / a);
+                std::normal_distribution<> ln(0.0, 1.0);
+                const double u = ln(lr) * sigma_u;
+                const double v = std::max(std::abs(ln(lr)), 1e-10);
+                step[k] = clip(u / std::pow(v, 1.0 / a), -100.0, 100.0);
+            }
+            const double step_scale = 0.01 * (1.0 - stagnation / static_cast<double>(cfg.max_stagnation));
+            for (int k = 0; k < P; ++k) p.x[k] = clip(p.x[k] + step_scale * (ub[k] - lb[k]) * step[k], lb[k], ub[k]);
+        }
+    };
+    auto restart = [&]() {  // restartSwarm :742-814, keep_best_count = 3
+        const int keep = 3;
+        std::sort(sw.begin(), sw.end(), [](const Ptl& a, const Ptl& b) { return a.pb > b.pb; });
+        const std::vector<Ptl> elite(sw.begin(), sw.begin() + std::min(keep, S));
+        const std::vector<unsigned int> sd = draw_seeds();
+        for (int i = keep; i < S; ++i) {
+            std::mt19937 lr(sd[i]);
+            std::uniform_real_distribution<> lu(0.0, 1.0);
+            std::normal_distribution<> ln(0.0, 1.0);
+            const Ptl& e = elite[static_cast<size_t>(i) % elite.size()];
+            Ptl& p = sw[i];
+            for (int k = 0; k < P; ++k) {
+                if (lu(lr) < 0.7) {
+                    const double sigma = 0.3 * (ub[k] - lb[k]) * (1.0 + 0.5 * lu(lr));
+                    p.x[k] = e.x[k] + sigma * ln(lr);
+                } else {
+                    p.x[k] = lb[k] + lu(lr) * (ub[k] - lb[k]);
+                }
+                p.x[k] = clip(p.x[k], lb[k], ub[k]);
+                const double vmax = 0.2 * (ub[k] - lb[k]);
+                p.v[k] = -vmax + 2 * vmax * lu(lr);
+            }
+            p.fit = f(p.x);
+            p.pb_x = p.x; p.pb = p.fit; p.q_x = p.x;
+            p.wins = 0; p.moves = 0; p.rate = 0.0;
+        }
+        for (int i = 0; i < std::min(keep, S); ++i) sw[i] = elite[i];
+        g = sw[0].pb; g_x = sw[0].pb_x;
+    };
+
+    double previous_g = -std::numeric_limits<double>::infinity();
+    for (int iter = 0; iter < cfg.iterations; ++iter) {  // :127-215
+        if (std::abs(g - previous_g) < cfg.restart_threshold) {
+            if (++stagnation > cfg.max_stagnation) { restart(); stagnation = 0; }
+        } else {
+            stagnation = 0;
+        }
+        previous_g = g;
+
+        // ---- updateParticles :330-432
+        double omega, c1, c2;
+        const double ratio = (cfg.iterations > 1) ? static_cast<double>(iter) / (cfg.iterations - 1) : 0.0;
+        if (cfg.use_adaptive_parameters) {
+            double mean_d = 0.0, max_d = 0.0;  // calculateEvolutionaryFactor :445-479
+            for (const Ptl& p : sw) {
+                double sq = 0.0;
+                for (int k = 0; k < P; ++k) sq += (p.x[k] - g_x[k]) * (p.x[k] - g_x[k]);
+                mean_d += std::sqrt(sq);
+                max_d = std::max(max_d, std::sqrt(sq));
+            }
+            mean_d /= S;
+            double mean_f = 0.0, max_f = -std::numeric_limits<double>::infinity(), min_f = std::numeric_limits<double>::infinity();
+            for (const Ptl& p : sw) { mean_f += p.fit; max_f = std::max(max_f, p.fit); min_f = std::min(min_f, p.fit); }
+            mean_f /= S;
+            const double range = (max_f - min_f) > 1e-10 ? (max_f - min_f) : 1e-10;
+            const double ef = 0.5 * ((max_d > 0) ? mean_d / max_d : 0.0) + 0.5 * (1.0 - (max_f - mean_f) / range);
+            if (ef > 0.7) { omega = 0.9 - 0.2 * ratio; c1 = 1.5 + 0.5 * std::sin(ratio * M_PI); c2 = 1.5 - 0.5 * std::sin(ratio * M_PI); }
+            else if (ef > 0.4) { omega = 0.7 - 0.3 * ratio; c1 = 2.0 - ratio; c2 = 1.0 + ratio; }
+            else if (ef > 0.2) { omega = 0.4 - 0.3 * ratio; c1 = 1.0 - 0.5 * ratio; c2 = 2.0 + 0.5 * ratio; }
+            else { omega = 0.9 + 0.1 * master_u(master); c1 = 2.5 + master_u(master); c2 = 0.5 + master_u(master); }
+            omega = clip(omega, 0.1, 1.0); c1 = clip(c1, 0.0, 4.0); c2 = clip(c2, 0.0, 4.0);
+        } else {
+            omega = cfg.omega_start + (cfg.omega_end - cfg.omega_start) * ratio;
+            c1 = cfg.c1_initial + (cfg.c1_final - cfg.c1_initial) * ratio;
+            c2 = cfg.c2_initial + (cfg.c2_final - cfg.c2_initial) * ratio;
+        }
+        std::vector<double> mbest;
+        if (cfg.variant == 1 || cfg.variant == 4 /* deviation: see the header comment */) {
+            mbest.assign(P, 0.0);
+            for (const Ptl& p : sw) for (int k = 0; k < P; ++k) mbest[k] += p.pb_x[k];
+            for (double& m : mbest) m /= S;
+        }
+        const std::vector<unsigned int> sd = draw_seeds();
+        // deferred: every neighbourhood best is read before the first particle moves.  The RANDOM_DYNAMIC
+        // topology's shuffles draw from the master generator in particle order either way.
+        std::vector<std::vector<double>> lbests;
+        if (cfg.deferred_personal_bests)
+            for (int i = 0; i < S; ++i) lbests.push_back(cfg.topology == 0 ? g_x : neighbourhood_best(i));
+        for (int i = 0; i < S; ++i) {
+            Ptl& p = sw[i];
+            std::mt19937 lr(sd[i]);
+            std::uniform_real_distribution<> lu(0.0, 1.0);
+            const std::vector<double> lbest =
+                cfg.deferred_personal_bests ? lbests[i] : (cfg.topology == 0 ? g_x : neighbourhood_best(i));
+            if (cfg.variant == 0 || cfg.variant == 2) move_standard(p, lbest, omega, c1, c2, lr);
+            else if (cfg.variant == 1) move_quantum(p, mbest, iter, lr);
+            else if (cfg.variant == 3) move_levy(p, omega, c1, c2, lr);
+            else {
+                if (p.rate < 0.3 && lu(lr) < 0.5) move_levy(p, omega, c1, c2, lr);
+                else if (p.rate > 0.7 && lu(lr) < 0.3) move_quantum(p, mbest, iter, lr);
+                else move_standard(p, lbest, omega, c1, c2, lr);
+            }
+            const double nf = f(p.x);
+            p.fit = nf;
+            p.moves++;
+            if (nf > p.pb) { p.pb = nf; p.pb_x = p.x; p.wins++; }
+            p.rate = p.moves > 0 ? static_cast<double>(p.wins) / p.moves : 0.0;
+        }
+        for (const Ptl& p : sw) if (p.pb > g) { g = p.pb; g_x = p.pb_x; }  // :148-155
+
+        if ((cfg.variant == 2 || cfg.variant == 4) && iter % 5 == 0) {  // ELS :158-179, :706-740
+            auto it = std::max_element(sw.begin(), sw.end(), [](const Ptl& a, const Ptl& b) { return a.pb < b.pb; });
+            Ptl& b = *it;
+            std::vector<double> trial = b.x;
+            double sigma_scale = 0.1 * std::exp(-2.0 * b.rate);
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                for (int k = 0; k < P; ++k)
+                    trial[k] = clip(b.x[k] + sigma_scale * (ub[k] - lb[k]) * master_n(master), lb[k], ub[k]);
+                const double tf = f(trial);
+                if (tf > b.pb) { b.x = trial; b.pb_x = trial; b.pb = tf; b.fit = tf; break; }
+                sigma_scale *= 0.5;
+            }
+            if (b.pb > g) { g = b.pb; g_x = b.pb_x; }
+        }
+        r.best_trace.push_back(g);
+    }
+    r.best = g_x;
+    r.best_value = g;
+    std::vector<double> mean(P, 0.0);  // :221-239
+    for (const Ptl& p : sw) for (int k = 0; k < P; ++k) mean[k] += p.pb_x[k];
+    for (double& m : mean) m /= S;
+    r.final_cov.assign(static_cast<size_t>(P) * P, 0.0);
+    for (const Ptl& p : sw)
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) r.final_cov[a * P + b] += (p.pb_x[a] - mean[a]) * (p.pb_x[b] - mean[b]);
+    for (double& c : r.final_cov) c /= (S - 1);
+    for (int a = 0; a < P; ++a) r.final_cov[a * P + a] += 1e-6;
+    return r;
+}
+
+// -----------------------------------------------------------------------------
 // BASELINE config 0 ("plumbing", CPU only): the age-structured SIR model behind the same interfaces,
 // AgeSIRModel::computeDerivatives (src/sir_age_structured/AgeSIRModel.cpp:106-139):
 //   lambda = q (C_current (I / N)) with I/N = 0 where N <= 1e-9, clipped at 0; dS = -lambda S,

@@ -112,6 +112,52 @@ def test_batched_hill_climbing_follows_the_serial_search(mm, oracle_py, shipped)
     assert np.array_equal(scalar["trace"], got["trace"]) and np.array_equal(scalar["best"], got["best"])
 
 
+@pytest.mark.parametrize("settings", [
+    dict(),                                                                     # the reference's defaults
+    dict(variant=1),                                                            # quantum-behaved
+    dict(variant=3),                                                            # Levy flight
+    dict(variant=2, use_adaptive_parameters=1),                                 # adaptive + elitist learning
+    dict(variant=4, use_adaptive_parameters=1, use_opposition_learning=1),      # hybrid
+    dict(variant=4, topology=2, max_stagnation=2, restart_threshold=1e300),     # von Neumann grid + restarts
+    dict(topology=1), dict(topology=3),                                         # ring, random dynamic
+], ids=["standard", "quantum", "levy", "adaptive", "hybrid-obl", "hybrid-grid-restart", "ring", "random"])
+def test_batched_particle_swarm_follows_the_serial_swarm(mm, oracle_py, shipped, settings):
+    """BatchedParticleSwarmOptimization (one launch per swarm phase) against the one-particle-at-a-time restatement
+    of ParticleSwarmOptimizer.cpp:105-948 in the oracle, same seed.  With the GLOBAL_BEST topology the oracle runs
+    the reference's serial order; the other topologies read neighbours' personal bests inside the loop, so there
+    the oracle is told to defer the personal-best updates as the batched evaluation does."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=0)
+    iters, swarm, seed = 14, 12, 21
+    deferred = int(settings.get("topology", 0) != 0)
+    ref = oracle_py.Oracle(pb).particle_swarm(pb.base_theta, seed, iterations=iters, swarm_size=swarm,
+                                              deferred_personal_bests=deferred, **settings)
+    got = mm.HostObjective(pb).particle_swarm(pb.base_theta, seed, iterations=iters, swarm_size=swarm, **settings)
+    np.testing.assert_allclose(got["trace"], ref["trace"], rtol=1e-10)
+    np.testing.assert_allclose(got["best"], ref["best"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got["final_cov"], ref["final_cov"], rtol=1e-9, atol=1e-18)
+    assert got["evaluations"] == ref["evaluations"]
+    assert np.all(np.diff(got["trace"]) >= 0) and got["best_value"] == got["trace"][-1]
+    # one launch per swarm phase (+ the elitist trials, one value each): far fewer launches than values
+    assert got["launches"] <= 2 + iters + 3 * (iters // 5 + 1) + iters // 2
+    assert got["launches"] < got["evaluations"] / 4
+
+
+def test_particle_swarm_shipped_settings_and_errors(mm, shipped):
+    """data/configuration/pso_settings.txt ships swarm_size 1, iterations 1: the run is two evaluations and the
+    covariance divides by swarm_size - 1 = 0 (ParticleSwarmOptimizer.cpp:233) -- kept, not papered over."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=0)
+    host = mm.HostObjective(pb)
+    got = host.particle_swarm(pb.base_theta, 1, iterations=1, swarm_size=1, omega_start=0.9, omega_end=0.4,
+                              c1_initial=1.5, c1_final=1.5, c2_initial=1.5, c2_final=1.5, report_interval=1)
+    assert got["evaluations"] == 2 and got["launches"] == 2
+    assert not np.all(np.isfinite(got["final_cov"]))
+    np.testing.assert_allclose(got["trace"][0], max(host.calculate(pb.base_theta), got["best_value"]), rtol=1e-12)
+    for bad in (dict(iterations=0), dict(swarm_size=0), dict(variant=5), dict(topology=4), dict(omega_start=-1),
+                dict(max_stagnation=0)):
+        with pytest.raises(RuntimeError):
+            host.particle_swarm(pb.base_theta, 1, **bad)
+
+
 def test_two_phase_calibration_follows_the_reference_flow(mm, oracle_py, shipped):
     """HipModelCalibrator (ModelCalibrator.cpp:47-159): HC in clamp mode -> conditioned covariance ->
     MH in reflect mode -> objective value of every stored sample; chain 0 of a 3-chain run walks the

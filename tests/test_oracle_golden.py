@@ -218,3 +218,38 @@ def test_hill_climbing_restatement_properties(oracle_py, shipped):
     assert np.allclose(a["final_cov"], a["final_cov"].T, rtol=0, atol=0)
     lo, hi, has = shipped.bounds_arrays()
     assert np.all(a["best"][has.astype(bool)] >= lo[has.astype(bool)]) and np.all(a["best"][has.astype(bool)] <= hi[has.astype(bool)])
+
+
+def test_particle_swarm_restatement_properties(oracle_py, shipped):
+    """oracle::particle_swarm (ParticleSwarmOptimizer.cpp:105-948): determinism, monotone global best, bounds,
+    and that with the GLOBAL_BEST topology the serial order and the deferred order are the same search."""
+    orc = oracle_py.Oracle(shipped)
+    kw = dict(iterations=6, swarm_size=8)
+    a = orc.particle_swarm(shipped.base_theta, 3, **kw)
+    b = orc.particle_swarm(shipped.base_theta, 3, **kw)
+    c = orc.particle_swarm(shipped.base_theta, 4, **kw)
+    assert np.array_equal(a["trace"], b["trace"]) and not np.array_equal(a["best"], c["best"])
+    assert np.all(np.diff(a["trace"]) >= 0) and a["best_value"] == a["trace"][-1]
+    assert a["evaluations"] == 8 * (1 + 6)
+    lo, hi, _ = shipped.bounds_arrays()
+    assert np.all(a["best"] >= lo) and np.all(a["best"] <= hi)
+    assert np.array_equal(a["final_cov"], a["final_cov"].T) and np.all(np.diag(a["final_cov"]) >= 1e-6)
+    # warm start: particle 0 is the given vector, so the first global best is at least its value
+    assert a["trace"][0] >= orc.calculate(shipped.base_theta)
+    for variant in (0, 1, 3, 4):
+        s = orc.particle_swarm(shipped.base_theta, 5, variant=variant, **kw)
+        d = orc.particle_swarm(shipped.base_theta, 5, variant=variant, deferred_personal_bests=1, **kw)
+        assert np.array_equal(s["trace"], d["trace"]) and np.array_equal(s["final_cov"], d["final_cov"]), variant
+    # a ring topology reads neighbours' personal bests inside the loop: the two orders are different searches
+    s = orc.particle_swarm(shipped.base_theta, 5, topology=1, iterations=12, swarm_size=8)
+    d = orc.particle_swarm(shipped.base_theta, 5, topology=1, iterations=12, swarm_size=8, deferred_personal_bests=1)
+    assert not np.array_equal(s["final_cov"], d["final_cov"])
+    # adaptive variant: elitist learning adds up to three evaluations on iterations 0 and 5
+    e = orc.particle_swarm(shipped.base_theta, 5, variant=2, use_adaptive_parameters=1, **kw)
+    assert 8 * 7 + 2 <= e["evaluations"] <= 8 * 7 + 6
+    # stagnation restart keeps three elite particles and re-draws the rest (one extra evaluation each)
+    r = orc.particle_swarm(shipped.base_theta, 5, iterations=6, swarm_size=8, max_stagnation=1, restart_threshold=1e300)
+    assert r["evaluations"] == 8 * 7 + 2 * 5 and np.all(np.diff(r["trace"]) >= 0)
+    # opposition learning re-evaluates the selected swarm once
+    o = orc.particle_swarm(shipped.base_theta, 5, use_opposition_learning=1, **kw)
+    assert o["evaluations"] == 8 * 8
