@@ -13,6 +13,7 @@
 // iteration here (eigenpairs ascending, like Eigen returns them).
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,10 @@ class HipModelCalibrator {
 public:
     // evaluates the initial objective value like the reference's constructor (:36-45)
     HipModelCalibrator(HipSEPAIHRDParameterManager& parameterManager, HipSEPAIHRDObjectiveFunction& objective);
+    // Phase-1 algorithm, as the map the reference's constructor takes under PHASE1_NAME (ModelCalibrator.hpp:60):
+    // BatchedHillClimbingOptimizer unless set (runHillClimbingMCMC); BatchedParticleSwarmOptimization gives
+    // SEPAIHRDModelCalibration::runPSOMCMC (SEPAIHRDModelCalibration.cpp:179-208).
+    void setPhase1Algorithm(std::unique_ptr<IOptimizationAlgorithm> algorithm) { phase1_algo_ = std::move(algorithm); }
     void calibrate(const std::map<std::string, double>& phase1_settings,
                    const std::map<std::string, double>& phase2_settings, int chains = 1);
     const Eigen::VectorXd& getBestParameterVector() const { return best_; }
@@ -43,6 +48,7 @@ public:
 private:
     HipSEPAIHRDParameterManager& pm_;
     HipSEPAIHRDObjectiveFunction& obj_;
+    std::unique_ptr<IOptimizationAlgorithm> phase1_algo_;
     Eigen::VectorXd best_;
     double best_value_ = 0.0, initial_value_ = 0.0;
     OptimizationResult phase1_;

@@ -102,9 +102,9 @@ void HipModelCalibrator::calibrate(const std::map<std::string, double>& phase1_s
     const int C = std::max(1, chains);
     // phase 1 (:57-77)
     pm_.setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);
-    BatchedHillClimbingOptimizer hc;
-    hc.configure(phase1_settings);
-    phase1_ = hc.optimize(best_, obj_, pm_);
+    if (!phase1_algo_) phase1_algo_ = std::make_unique<BatchedHillClimbingOptimizer>();
+    phase1_algo_->configure(phase1_settings);
+    phase1_ = phase1_algo_->optimize(best_, obj_, pm_);
     if (phase1_.bestObjectiveValue > best_value_) {
         best_value_ = phase1_.bestObjectiveValue;
         best_ = phase1_.bestParameters;

@@ -336,6 +336,33 @@ int host_pso_run(void* hv, const double* x0, const char* const* keys, const doub
     }
 }
 
+namespace {
+void copy_calibration(const HipModelCalibrator& cal, int P, int mh_iterations, double* best, double* best_value,
+                      double* initial_value, double* phase1_best_value, double* phase2_cov, unsigned char* accept_trace,
+                      double* samples, double* sample_values, double* mcmc_objective_values, int32_t* n_samples) {
+    for (int i = 0; i < P; ++i) best[i] = cal.getBestParameterVector()[i];
+    *best_value = cal.getBestObjectiveValue();
+    if (initial_value) *initial_value = cal.getInitialObjectiveValue();
+    if (phase1_best_value) *phase1_best_value = cal.getPhase1Result().bestObjectiveValue;
+    if (phase2_cov)
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) phase2_cov[static_cast<size_t>(a) * P + b] = cal.getPhase2Covariance()(a, b);
+    const auto& res = cal.getPhase2Results();
+    const int ns = static_cast<int>(res[0].samples.size());
+    if (n_samples) *n_samples = ns;
+    for (size_t c = 0; c < res.size(); ++c) {
+        if (accept_trace)
+            std::copy(cal.acceptTraces()[c].begin(), cal.acceptTraces()[c].end(), accept_trace + c * static_cast<size_t>(mh_iterations - 1));
+        for (int s = 0; s < ns; ++s) {
+            if (samples)
+                for (int i = 0; i < P; ++i) samples[(c * ns + s) * P + i] = res[c].samples[static_cast<size_t>(s)][i];
+            if (sample_values) sample_values[c * ns + s] = res[c].sampleObjectiveValues[static_cast<size_t>(s)];
+        }
+    }
+    if (mcmc_objective_values) std::copy(cal.getMCMCObjectiveValues().begin(), cal.getMCMCObjectiveValues().end(), mcmc_objective_values);
+}
+}  // namespace
+
 // HipModelCalibrator: two-phase calibration.  Per-chain outputs are chain-major; n_samples is per chain.
 int host_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
                    int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed, int chains,
@@ -353,26 +380,36 @@ int host_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int t
                        {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                        {"seed", double(mh_seed)}, {"store_samples", 1.0}},
                       chains);
-        for (int i = 0; i < P; ++i) best[i] = cal.getBestParameterVector()[i];
-        *best_value = cal.getBestObjectiveValue();
-        if (initial_value) *initial_value = cal.getInitialObjectiveValue();
-        if (phase1_best_value) *phase1_best_value = cal.getPhase1Result().bestObjectiveValue;
-        if (phase2_cov)
-            for (int a = 0; a < P; ++a)
-                for (int b = 0; b < P; ++b) phase2_cov[static_cast<size_t>(a) * P + b] = cal.getPhase2Covariance()(a, b);
-        const auto& res = cal.getPhase2Results();
-        const int ns = static_cast<int>(res[0].samples.size());
-        if (n_samples) *n_samples = ns;
-        for (size_t c = 0; c < res.size(); ++c) {
-            if (accept_trace)
-                std::copy(cal.acceptTraces()[c].begin(), cal.acceptTraces()[c].end(), accept_trace + c * static_cast<size_t>(mh_iterations - 1));
-            for (int s = 0; s < ns; ++s) {
-                if (samples)
-                    for (int i = 0; i < P; ++i) samples[(c * ns + s) * P + i] = res[c].samples[static_cast<size_t>(s)][i];
-                if (sample_values) sample_values[c * ns + s] = res[c].sampleObjectiveValues[static_cast<size_t>(s)];
-            }
-        }
-        if (mcmc_objective_values) std::copy(cal.getMCMCObjectiveValues().begin(), cal.getMCMCObjectiveValues().end(), mcmc_objective_values);
+        copy_calibration(cal, P, mh_iterations, best, best_value, initial_value, phase1_best_value, phase2_cov, accept_trace,
+                         samples, sample_values, mcmc_objective_values, n_samples);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// SEPAIHRDModelCalibration::runPSOMCMC (SEPAIHRDModelCalibration.cpp:179-208): phase 1 = particle swarm.
+int host_calibrate_pso(void* hv, const char* const* keys, const double* values, int n_settings, int mh_iterations,
+                       int burn_in, int adaptation_period, int thinning, uint32_t mh_seed, int chains, double* best,
+                       double* best_value, double* initial_value, double* phase1_best_value, double* phase2_cov,
+                       unsigned char* accept_trace, double* samples, double* sample_values,
+                       double* mcmc_objective_values, int32_t* n_samples) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        h->pm->setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);
+        std::map<std::string, double> phase1;
+        for (int i = 0; i < n_settings; ++i) phase1[keys[i]] = values[i];
+        HipModelCalibrator cal(*h->pm, *h->obj);
+        cal.setPhase1Algorithm(std::make_unique<BatchedParticleSwarmOptimization>());
+        cal.calibrate(phase1,
+                      {{"mcmc_iterations", double(mh_iterations)}, {"burn_in", double(burn_in)},
+                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
+                       {"seed", double(mh_seed)}, {"store_samples", 1.0}},
+                      chains);
+        copy_calibration(cal, P, mh_iterations, best, best_value, initial_value, phase1_best_value, phase2_cov, accept_trace,
+                         samples, sample_values, mcmc_objective_values, n_samples);
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

@@ -44,6 +44,8 @@ def load_library() -> C.CDLL:
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.host_calibrate_pso.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_pso_run.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
                                   vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -148,6 +150,30 @@ class HostObjective:
         n = ns.value
         assert n == cap, (n, cap)
         out.update(best_value=bv.value, initial_value=iv.value, phase1_best_value=p1.value, n_samples=n)
+        return out
+
+    def calibrate_pso(self, pso_settings: dict, mh_seed: int, mh_iterations: int, burn_in: int,
+                      adaptation_period: int = 100, thinning: int = 1, chains: int = 1) -> dict:
+        """HipModelCalibrator with the particle swarm as phase 1 (SEPAIHRDModelCalibration::runPSOMCMC)."""
+        cap = 1 + (mh_iterations - 1) // max(1, thinning)
+        out = {"best": np.empty(self.P), "phase2_cov": np.empty((self.P, self.P)),
+               "accept_trace": np.empty((chains, mh_iterations - 1), dtype=np.uint8),
+               "samples": np.empty((chains, cap, self.P)), "sample_values": np.empty((chains, cap)),
+               "mcmc_objective_values": np.empty((chains, cap))}
+        keys = (C.c_char_p * len(pso_settings))(*[k.encode() for k in pso_settings])
+        vals = np.array([float(v) for v in pso_settings.values()])
+        bv, iv, p1 = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        ns = C.c_int32(0)
+        rc = self.lib.host_calibrate_pso(self.h, keys, vals.ctypes.data, len(pso_settings), mh_iterations, burn_in,
+                                         adaptation_period, thinning, mh_seed, chains, out["best"].ctypes.data,
+                                         C.byref(bv), C.byref(iv), C.byref(p1), out["phase2_cov"].ctypes.data,
+                                         out["accept_trace"].ctypes.data, out["samples"].ctypes.data,
+                                         out["sample_values"].ctypes.data, out["mcmc_objective_values"].ctypes.data,
+                                         C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("host_calibrate_pso: " + self.lib.host_last_error().decode())
+        assert ns.value == cap, (ns.value, cap)
+        out.update(best_value=bv.value, initial_value=iv.value, phase1_best_value=p1.value, n_samples=ns.value)
         return out
 
     def posterior_ensemble(self, samples, num_for_ppc: int, seed: int, burn_in: int = 0, thinning: int = 1,

@@ -181,6 +181,27 @@ def test_two_phase_calibration_follows_the_reference_flow(mm, oracle_py, shipped
     assert got["best_value"] >= ref["best_value"] * (1 - 1e-10)
 
 
+def test_swarm_then_sampler_calibration(mm, oracle_py, shipped):
+    """SEPAIHRDModelCalibration::runPSOMCMC (SEPAIHRDModelCalibration.cpp:179-208): the swarm is phase 1 of the same
+    ModelCalibrator flow -- its best vector starts the chains, its personal-best covariance is conditioned
+    (ModelCalibrator.cpp:93-131) and handed to the sampler."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=0)
+    pso = dict(iterations=10, swarm_size=16, seed=8)
+    orc = oracle_py.Oracle(pb)
+    ref1 = orc.particle_swarm(pb.base_theta, 8, iterations=10, swarm_size=16)
+    got = mm.HostObjective(pb).calibrate_pso(pso, mh_seed=9, mh_iterations=200, burn_in=50, adaptation_period=50,
+                                             thinning=2, chains=2)
+    np.testing.assert_allclose(got["phase1_best_value"], ref1["best_value"], rtol=1e-10)
+    np.testing.assert_allclose(got["phase2_cov"], orc.condition_covariance(ref1["final_cov"]), rtol=1e-8, atol=1e-20)
+    # the chains start at the overall best so far: the swarm's, or the initial guess when the swarm found nothing better
+    start = ref1["best"] if ref1["best_value"] > got["initial_value"] else pb.base_theta
+    np.testing.assert_allclose(got["samples"][0, 0], start, rtol=1e-12, atol=1e-14)
+    # phase 2 is the code path test_two_phase_calibration_follows_the_reference_flow pins against the oracle
+    assert 0 < got["accept_trace"][0].sum() < 199 and not np.array_equal(got["accept_trace"][0], got["accept_trace"][1])
+    assert got["n_samples"] == 100 and np.all(np.isfinite(got["mcmc_objective_values"]))
+    assert got["best_value"] >= max(ref1["best_value"], got["initial_value"]) * (1 - 1e-10)
+
+
 def _multiplier_fixture(mm, ref_fixture):
     """reference test fixture + calibrated E0 / I0 multipliers (the finite-difference objective reads them)."""
     pb = ref_fixture

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end calibration run on the device path, shaped like the reference's `main --algorithm hill`
-(src/model/main.cpp:383-560): Hill-Climbing phase -> conditioned covariance -> Adaptive-Metropolis chains ->
+"""End-to-end calibration run on the device path, shaped like the reference's `main --algorithm hill` / `--algorithm
+pso` (src/model/main.cpp:383-560): Hill-Climbing or particle-swarm phase -> conditioned covariance -> Adaptive-Metropolis chains ->
 posterior trace files in the sampler's CSV format (MetropolisHastingsSampler.cpp:414-438) -> post-calibration
 ensemble (posterior predictive quantiles, seroprevalence and Rt trajectories, per-sample metric table).
 
@@ -33,6 +33,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--problem", default=os.path.join(ROOT, "tests", "golden", "shipped_problem.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "calibration"))
+    ap.add_argument("--algorithm", choices=["hill", "pso"], default="hill")
+    ap.add_argument("--pso-iterations", type=int, default=100)
+    ap.add_argument("--swarm-size", type=int, default=256)
+    ap.add_argument("--pso-variant", type=int, default=0)
+    ap.add_argument("--pso-topology", type=int, default=0)
     ap.add_argument("--chains", type=int, default=16)
     ap.add_argument("--hc-iterations", type=int, default=60)
     ap.add_argument("--hc-threads", type=int, default=16)
@@ -52,10 +57,16 @@ def main():
     host = mm.HostObjective(pb)
 
     t0 = time.perf_counter()
-    cal = host.calibrate(hc_seed=args.seed, mh_seed=args.seed + 1, hc_iterations=args.hc_iterations,
-                         mh_iterations=args.mcmc_iterations, burn_in=args.burn_in,
-                         cloud_size_multiplier=args.cloud_size_multiplier, threads=args.hc_threads,
-                         adaptation_period=args.adaptation_period, thinning=args.thinning, chains=args.chains)
+    if args.algorithm == "pso":
+        cal = host.calibrate_pso(dict(iterations=args.pso_iterations, swarm_size=args.swarm_size, variant=args.pso_variant,
+                                      topology=args.pso_topology, seed=args.seed),
+                                 mh_seed=args.seed + 1, mh_iterations=args.mcmc_iterations, burn_in=args.burn_in,
+                                 adaptation_period=args.adaptation_period, thinning=args.thinning, chains=args.chains)
+    else:
+        cal = host.calibrate(hc_seed=args.seed, mh_seed=args.seed + 1, hc_iterations=args.hc_iterations,
+                           mh_iterations=args.mcmc_iterations, burn_in=args.burn_in,
+                           cloud_size_multiplier=args.cloud_size_multiplier, threads=args.hc_threads,
+                           adaptation_period=args.adaptation_period, thinning=args.thinning, chains=args.chains)
     t_cal = time.perf_counter() - t0
     for c in range(args.chains):
         mm.config_io.write_posterior_trace_csv(os.path.join(args.out, f"posterior_trace_chain{c}.csv"), cal["samples"][c],
@@ -99,7 +110,7 @@ def main():
 
     evals = args.chains * args.mcmc_iterations
     summary = {"initial_value": cal["initial_value"], "phase1_best_value": cal["phase1_best_value"],
-               "best_value": cal["best_value"], "chains": args.chains, "mcmc_iterations": args.mcmc_iterations,
+               "best_value": cal["best_value"], "algorithm": args.algorithm, "chains": args.chains, "mcmc_iterations": args.mcmc_iterations,
                "acceptance_rate_mean": float(cal["accept_trace"].mean()), "calibration_seconds": t_cal,
                "proposals_per_s": evals / t_cal, "ensemble_samples": int(len(pooled)), "ensemble_valid": int(ens["n_valid"]),
                "ensemble_seconds": t_ens, "median_R0": float(np.nanmedian(ens["metrics"][:, 0])), "out": args.out}
