@@ -260,9 +260,12 @@ def main():
     if rank == 0:
         evals_total = world * B * K
         value = evals_total / elapsed_max
-        info = hip.kernel_info()
+        info = hip.kernel_info(B)
         bytes_eval = 8 * P + 16 + problem_bytes(pb) / B        # theta in, loglik + counters out
-        split_ll = -(-B // info["chains_per_wave"]) <= 1024   # batches that do not fill the chip park increments
+        # csrc/sepaihrd_device.h split_likelihood(): batches that do not fill the chip, and Dopri5 in tolerance mode at
+        # any size, park the daily increments for a separate likelihood pass
+        waves4 = -(-B // (64 // max(1, 1 << (pb.n - 1).bit_length())))
+        split_ll = waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)
         ws_bytes_eval = pb.n_times * 3 * pb.n * 8 if split_ll else 0
         bytes_launch = bytes_eval * B
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9

@@ -685,16 +685,16 @@ int sepaihrd_apply_constraints(const sepaihrd_ctx* ctx, int mode, const double* 
     return SEPAIHRD_OK;
 }
 
-int sepaihrd_get_kernel_info(sepaihrd_ctx* ctx, sepaihrd_kernel_info* info) {
+int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx* ctx, int32_t batch_chains, sepaihrd_kernel_info* info) {
     if (!ctx || !info) return SEPAIHRD_E_INVALID_ARG;
     std::memset(info, 0, sizeof(*info));
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     LaunchInfo li{};
-    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? kernel_info_fma(ctx->dp, ctx->solver, &li)
-                                                     : kernel_info_strict(ctx->dp, ctx->solver, &li);
+    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? kernel_info_fma(ctx->dp, ctx->solver, batch_chains, &li)
+                                                     : kernel_info_strict(ctx->dp, ctx->solver, batch_chains, &li);
     if (rc != 0) { ctx->last_error = "kernel_info failed"; return SEPAIHRD_E_HIP; }
-    info->lanes_per_chain = ctx->dp.lpc;
-    info->chains_per_wave = WAVE / ctx->dp.lpc;
+    info->lanes_per_chain = li.lanes_per_chain;
+    info->chains_per_wave = WAVE / li.lanes_per_chain;
     info->block_threads = WAVE;
     info->vgprs = li.vgprs; info->sgprs = li.sgprs; info->scratch_bytes = li.scratch;
     info->lds_bytes = li.lds_static + (int)eval_lds_bytes(ctx->dp);
@@ -702,10 +702,14 @@ int sepaihrd_get_kernel_info(sepaihrd_ctx* ctx, sepaihrd_kernel_info* info) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device), ctx, return SEPAIHRD_E_HIP);
     info->num_cus = prop.multiProcessorCount;
-    std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s lpc=%d solver=%d", li.name, ctx->dp.lpc,
+    std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s lpc=%d solver=%d", li.name, li.lanes_per_chain,
                   ctx->solver);
     std::snprintf(info->device_name, sizeof(info->device_name), "%s (%s)", prop.name, prop.gcnArchName);
     return SEPAIHRD_OK;
+}
+
+int sepaihrd_get_kernel_info(sepaihrd_ctx* ctx, sepaihrd_kernel_info* info) {
+    return sepaihrd_get_kernel_info_for_batch(ctx, 0, info);
 }
 
 // ------------------------------------------------------------------ device-resident Adaptive Metropolis

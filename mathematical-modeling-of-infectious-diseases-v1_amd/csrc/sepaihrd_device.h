@@ -75,6 +75,7 @@ inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { retu
 
 struct LaunchInfo {
     int vgprs, sgprs, lds_static, scratch, max_blocks_per_cu;
+    int lanes_per_chain;  // of the kernel a launch of the given batch uses
     const char* name;
 };
 
@@ -83,8 +84,9 @@ int launch_eval_strict(const DevProblem& pb, int solver, const double* d_theta, 
                        const EvalOutputs& out, void* stream);
 int launch_eval_fma(const DevProblem& pb, int solver, const double* d_theta, int B,
                     const EvalOutputs& out, void* stream);
-int kernel_info_strict(const DevProblem& pb, int solver, LaunchInfo* info);
-int kernel_info_fma(const DevProblem& pb, int solver, LaunchInfo* info);
+// batch <= 0: the large-batch kernel
+int kernel_info_strict(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
+int kernel_info_fma(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
 
 // ---- posterior ensemble summaries (csrc/sepaihrd_ensemble.hip) ----
 constexpr int ENSEMBLE_MAX_SAMPLES = 16384;  // one sorted segment lives in LDS (128 KiB of 160 KiB)

@@ -39,6 +39,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <utility>
 
@@ -71,16 +72,26 @@ __device__ __forceinline__ double dpp_move(double v) {
 // arithmetic, set its pace).
 template <int LA, int BA, int LB, int BB>
 __device__ __forceinline__ double dpp_bcast_row(double v) {
-    const int slo = __double2loint(v), shi = __double2hiint(v);
-    // first move into ALL banks (no "old" value to materialise), the second overwrites banks BB only
-    int lo = __builtin_amdgcn_mov_dpp(slo, 0x150 + LA, 0xf, 0xf, true);
-    int hi = __builtin_amdgcn_mov_dpp(shi, 0x150 + LA, 0xf, 0xf, true);
+    // row_newbcast is the one DPP control the double-precision ALU accepts on 64-bit operands (gfx90a+):
+    // v_mov_b64_dpp, one instruction per value.  First move into ALL banks (no "old" value to materialise), the
+    // second overwrites banks BB only.
     (void)BA;
-    if constexpr (BB != 0) {
-        lo = __builtin_amdgcn_update_dpp(lo, slo, 0x150 + LB, 0xf, BB, false);
-        hi = __builtin_amdgcn_update_dpp(hi, shi, 0x150 + LB, 0xf, BB, false);
-    }
-    return __hiloint2double(hi, lo);
+    double r = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + LA, 0xf, 0xf, true);
+    if constexpr (BB != 0) r = __builtin_amdgcn_update_dpp(r, v, 0x150 + LB, 0xf, BB, false);
+    return r;
+}
+
+// acc += m * (lane LANE of src's 16-lane row), in the lanes of banks BANKS: v_fmac_f64 with its first source through
+// DPP row_newbcast -- the broadcast costs no instruction of its own.  Inline asm is opaque to the hazard pass, so the
+// first term of a chain carries the two wait states a DPP read needs after the VALU write of `src`.
+template <int LANE, int BANKS, bool FIRST>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double src, double m) {
+    if constexpr (FIRST)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
+            : "+v"(acc) : "v"(src), "v"(m), "n"(LANE), "n"(BANKS));
+    else
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
+            : "+v"(acc) : "v"(src), "v"(m), "n"(LANE), "n"(BANKS));
 }
 
 // value held by lane J of my chain group
@@ -176,9 +187,13 @@ constexpr double db1 = 37.0 / 378 - 2825.0 / 27648, db3 = 250.0 / 621 - 18575.0 
 // tolerance mode folds per-chain constants once per evaluation instead of once per RHS call:
 //   MF_H_INFEC := h_infec / N, the contact row := a_i M(i, .), MF_R_I := gamma_I + h + d_community,
 //   MF_R_H := gamma_H + d_H + icu, MF_R_ICU := gamma_ICU + d_ICU  (8 instructions fewer per call)
+//   MF_PG := p gamma_p, MF_PI := gamma_p - p gamma_p.
+// The derivatives are written with explicit fma() in ONE fixed association, the one the 16-lane small-batch form
+// (sepaihrd_lane_split.inc) evaluates, so that a chain's result does not depend on which of the two kernels -- i.e.
+// on which batch size -- evaluated it.
 enum ModelField { MF_THETA = 0, MF_SIGMA, MF_GAMMA_P, MF_GAMMA_A, MF_GAMMA_I, MF_GAMMA_H, MF_GAMMA_ICU, MF_A,
                   MF_H_INFEC, MF_P, MF_H, MF_ICU, MF_D_H, MF_D_ICU, MF_D_COMM, MF_INV_N, MF_R_I, MF_R_H, MF_R_ICU,
-                  MF_MROW0 };
+                  MF_PG, MF_PI, MF_MROW0 };
 #else
 enum ModelField { MF_THETA = 0, MF_SIGMA, MF_GAMMA_P, MF_GAMMA_A, MF_GAMMA_I, MF_GAMMA_H, MF_GAMMA_ICU, MF_A,
                   MF_H_INFEC, MF_P, MF_H, MF_ICU, MF_D_H, MF_D_ICU, MF_D_COMM, MF_INV_N, MF_MROW0 };
@@ -196,18 +211,43 @@ template <int LPC>
 __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[NUM_COMP],
                                     double (&dx)[NUM_COMP], double beta_eff) {
     const double S = x[0], E = x[1], P = x[2], A = x[3], I = x[4], H = x[5], ICU = x[6];
-    const double total_inf = P + A + q.get(MF_THETA) * I;
 #if SEPAIHRD_ARITH_FMA
+    const double total_inf = fma(q.get(MF_THETA), I, P + A);
     const double inf_pressure = total_inf * q.get(MF_H_INFEC);  // h_infec / N folded
 #else
+    const double total_inf = P + A + q.get(MF_THETA) * I;
     const double inf_pressure = total_inf * q.get(MF_H_INFEC) * q.get(MF_INV_N);
 #endif
     // lambda_i = 0.0 + M(i,0) pi_0 + M(i,1) pi_1 + ..., j ascending (column-major walk of the reference).
     // The leading "0.0 +" only turns a -0.0 first product into +0.0, which max(0.0, .) below does anyway.
+#if SEPAIHRD_ARITH_FMA
+    // fma(m_0, pi_0, +0.0) = round(m_0 pi_0), then fma(m_j, pi_j, .) for j = 1, 2, ...: written out, because left to
+    // itself the contraction pass fuses the FIRST product of "m0 pi0 + m1 pi1" and rounds the second
+    double lambda;
+    if constexpr (LPC == 8 || LPC == 16) {
+        lambda = 0.0;
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (([&] {
+                if constexpr (LPC == 16) {
+                    fmac_row_bcast<J, 0xf, J == 0>(lambda, inf_pressure, q.get(MF_MROW0 + J));
+                } else {  // two chains per row: lanes 0-7 take lane J, lanes 8-15 lane 8 + J
+                    fmac_row_bcast<J, 0x3, J == 0>(lambda, inf_pressure, q.get(MF_MROW0 + J));
+                    fmac_row_bcast<8 + J, 0xc, false>(lambda, inf_pressure, q.get(MF_MROW0 + J));
+                }
+            }()), ...);
+        }(std::make_integer_sequence<int, LPC>{});
+    } else {
+        lambda = q.get(MF_MROW0) * group_bcast<LPC, 0>(inf_pressure);
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            ((lambda = fma(q.get(MF_MROW0 + J + 1), group_bcast<LPC, J + 1>(inf_pressure), lambda)), ...);
+        }(std::make_integer_sequence<int, LPC - 1>{});
+    }
+#else
     double lambda = q.get(MF_MROW0) * group_bcast<LPC, 0>(inf_pressure);
     [&]<int... J>(std::integer_sequence<int, J...>) {
         ((lambda += q.get(MF_MROW0 + J + 1) * group_bcast<LPC, J + 1>(inf_pressure)), ...);
     }(std::make_integer_sequence<int, LPC - 1>{});
+#endif
 #if SEPAIHRD_ARITH_FMA
     lambda *= beta_eff;  // a_i folded into the contact row
 #else
@@ -216,6 +256,21 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     const double lambda_val = (0.0 < lambda) ? lambda : 0.0;  // std::max(0.0, lambda)
 
     const double flow_SE = lambda_val * S;
+#if SEPAIHRD_ARITH_FMA
+    const double flow_IH = q.get(MF_H) * I;        // also d CumH
+    const double flow_H_ICU = q.get(MF_ICU) * H;   // also d CumICU
+    dx[0] = -flow_SE;
+    dx[1] = fma(-q.get(MF_SIGMA), E, flow_SE);
+    dx[2] = fma(-q.get(MF_GAMMA_P), P, q.get(MF_SIGMA) * E);
+    dx[3] = fma(-q.get(MF_GAMMA_A), A, q.get(MF_PG) * P);
+    dx[4] = fma(-q.get(MF_R_I), I, q.get(MF_PI) * P);
+    dx[5] = fma(-q.get(MF_R_H), H, flow_IH);
+    dx[6] = fma(-q.get(MF_R_ICU), ICU, flow_H_ICU);
+    dx[7] = fma(q.get(MF_GAMMA_ICU), ICU, fma(q.get(MF_GAMMA_A), A, fma(q.get(MF_GAMMA_H), H, q.get(MF_GAMMA_I) * I)));
+    dx[8] = fma(q.get(MF_D_H), H, fma(q.get(MF_D_COMM), I, q.get(MF_D_ICU) * ICU));
+    dx[9] = flow_IH;
+    dx[10] = flow_H_ICU;
+#else
     const double flow_EP = q.get(MF_SIGMA) * E;
     const double flow_P_out = q.get(MF_GAMMA_P) * P;
     const double flow_PA = q.get(MF_P) * flow_P_out;
@@ -229,22 +284,17 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     dx[1] = flow_SE - flow_EP;
     dx[2] = flow_EP - flow_P_out;
     dx[3] = flow_PA - q.get(MF_GAMMA_A) * A;
-#if SEPAIHRD_ARITH_FMA
-    dx[4] = flow_PI - q.get(MF_R_I) * I;
-    dx[5] = flow_IH - q.get(MF_R_H) * H;
-    dx[6] = flow_H_ICU - q.get(MF_R_ICU) * ICU;
-#else
     const double I_out = flow_IR + flow_IH + flow_ID_community;
     const double H_out = q.get(MF_GAMMA_H) * H + q.get(MF_D_H) * H + flow_H_ICU;
     const double ICU_out = (q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU)) * ICU;
     dx[4] = flow_PI - I_out;
     dx[5] = flow_IH - H_out;
     dx[6] = flow_H_ICU - ICU_out;
-#endif
     dx[7] = q.get(MF_GAMMA_A) * A + flow_IR + q.get(MF_GAMMA_H) * H + q.get(MF_GAMMA_ICU) * ICU;
     dx[8] = q.get(MF_D_H) * H + q.get(MF_D_ICU) * ICU + flow_ID_community;
     dx[9] = flow_IH;
     dx[10] = flow_H_ICU;
+#endif
 }
 
 // SEPAIHRDParameterManager.cpp:302-313 / :326-343
@@ -478,6 +528,8 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     q.set(MF_R_I, q.get(MF_GAMMA_I) + q.get(MF_H) + q.get(MF_D_COMM));
     q.set(MF_R_H, q.get(MF_GAMMA_H) + q.get(MF_D_H) + q.get(MF_ICU));
     q.set(MF_R_ICU, q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU));
+    q.set(MF_PG, q.get(MF_P) * q.get(MF_GAMMA_P));
+    q.set(MF_PI, q.get(MF_GAMMA_P) - q.get(MF_PG));
     SEP_UNROLL
     for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, q.get(MF_A) * pb.Mrow[age * LPC + j]);
 #else
@@ -1029,6 +1081,20 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProbl
     (void)valid;
 }
 
+#if SEPAIHRD_ARITH_FMA
+#include "sepaihrd_lane_split.inc"  // 16-lanes-per-chain form for small batches of the 4-age model
+
+// SEPAIHRD_LANE_SPLIT=0 keeps every launch on the 4-lane kernel, =1 uses the 16-lane form at any batch size
+// (measurement switches); unset: up to QUAD_MAX_CHAINS chains.
+inline bool lane_split_wanted(int B) {
+    static const int mode = [] {
+        const char* e = getenv("SEPAIHRD_LANE_SPLIT");
+        return e == nullptr ? -1 : atoi(e);
+    }();
+    return mode < 0 ? B <= QUAD_MAX_CHAINS : mode != 0;
+}
+#endif
+
 // ----------------------------------------------------------------------------------
 // launch plumbing
 // ----------------------------------------------------------------------------------
@@ -1059,6 +1125,11 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
+#if SEPAIHRD_ARITH_FMA
+    if constexpr (LPC == 4) {
+        if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
+    }
+#endif
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
     if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
@@ -1069,25 +1140,32 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     return launch_wps<LPC, SOLVER, 1, true>(pb, d_theta, blocks, B, out, stream);
 }
 
-template <int LPC, int SOLVER>
-int info_one(const DevProblem& pb, LaunchInfo* info, const char* name) {
-    constexpr int WPS = 1;
-    constexpr bool INLINE_LL = false;
+template <typename K>
+int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const char* name) {
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>)) !=
-        hipSuccess)
-        return -3;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) return -3;
     info->vgprs = attr.numRegs;
     info->sgprs = 0;
     info->lds_static = (int)attr.sharedSizeBytes;
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>, WAVE,
-                                                     eval_lds_bytes(pb)) != hipSuccess)
-        nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, WAVE, eval_lds_bytes(pb)) != hipSuccess) nb = -1;
     info->max_blocks_per_cu = nb;
+    info->lanes_per_chain = lanes;
     info->name = name;
     return 0;
+}
+
+template <int LPC, int SOLVER>
+int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
+#if SEPAIHRD_ARITH_FMA
+    if constexpr (LPC == 4) {
+        if (batch > 0 && lane_split_wanted(batch))
+            return info_of(&sepaihrd_eval_quad_kernel<SOLVER>, pb, QUAD_LANES, info, "sepaihrd_eval_quad_kernel[fma]");
+    }
+#endif
+    (void)batch;
+    return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name);
 }
 
 #define SEP_DISPATCH(FN, ...)                                                                  \
@@ -1116,8 +1194,8 @@ int SEP_LAUNCH(const DevProblem& pb, int solver, const double* d_theta, int B, c
                void* stream) {
     SEP_DISPATCH(launch_one, pb, d_theta, B, out, stream)
 }
-int SEP_INFO(const DevProblem& pb, int solver, LaunchInfo* info) {
-    SEP_DISPATCH(info_one, pb, info, SEP_NAME)
+int SEP_INFO(const DevProblem& pb, int solver, int batch, LaunchInfo* info) {
+    SEP_DISPATCH(info_one, pb, batch, info, SEP_NAME)
 }
 
 }  // namespace sepaihrd

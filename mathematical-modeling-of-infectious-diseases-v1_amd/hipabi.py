@@ -57,7 +57,7 @@ class sepaihrd_kernel_info(C.Structure):
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
-    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_reserve",
+    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
     "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
     "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_eval_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     lib.sepaihrd_get_kernel_info.argtypes = [vp, C.POINTER(sepaihrd_kernel_info)]
+    lib.sepaihrd_get_kernel_info_for_batch.argtypes = [vp, C.c_int32, C.POINTER(sepaihrd_kernel_info)]
     lib.sepaihrd_reserve.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_timing.argtypes = [vp, C.c_int]
     lib.sepaihrd_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -290,9 +291,10 @@ class HipObjective:
                                                         out.ctypes.data), "apply_constraints")
         return out
 
-    def kernel_info(self) -> dict:
+    def kernel_info(self, batch: int = 0) -> dict:
+        """Resource report of the integrator kernel a launch of `batch` chains uses (0: the large-batch kernel)."""
         info = sepaihrd_kernel_info()
-        self._check(self.lib.sepaihrd_get_kernel_info(self.ctx, C.byref(info)), "get_kernel_info")
+        self._check(self.lib.sepaihrd_get_kernel_info_for_batch(self.ctx, int(batch), C.byref(info)), "get_kernel_info")
         d = {k: getattr(info, k) for k, _ in info._fields_}
         d["kernel_name"] = info.kernel_name.decode()
         d["device_name"] = info.device_name.decode()

@@ -7,6 +7,8 @@ Tolerances (fp64):
     to 1e-9 relative (north-star bar: 1e-6), log-likelihood to 1e-10 relative.
   * fma arithmetic: contraction changes roundings; north-star bar 1e-6 relative on states.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -309,3 +311,21 @@ def test_minimal_problem_one_parameter_no_schedule(mm, oracle_py, ref_fixture):
     assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
     np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
     assert np.ptp(got["loglik"]) > 0  # the one parameter matters
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem,solver,chains", [("synth_400d_n4.json", 0, 1021), ("synth_400d_n4.json", 1, 1021),
+                                                   ("shipped_problem.json", 0, 37)])
+def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains):
+    """Up to 4096 chains the tolerance-mode build runs the 16-lanes-per-chain form of the integrator
+    (csrc/sepaihrd_lane_split.inc); SEPAIHRD_LANE_SPLIT=0 keeps the 4-lane kernel.  Same chains through both, in
+    two processes (the switch is read once): log-likelihood, status, step counts and every trajectory state are the
+    same bits -- a chain's result does not depend on the batch it was evaluated in.  1021 and 37 chains leave a
+    ragged last wave in both layouts."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "compare_lane_split.py")
+    r = subprocess.run([sys.executable, tool, "--problem", problem, "--solver", str(solver), "--chains", str(chains)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "traj: identical=True" in r.stdout and "n_accept: identical=True" in r.stdout

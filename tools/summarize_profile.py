@@ -16,7 +16,8 @@ except FileNotFoundError:
 # (third template argument: 1 = fma, 0 = strict)
 arith_flag = "1" if (bench or {}).get("config", {}).get("arith", "fma") == "fma" else "0"
 import re
-pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + ",")
+# ... or, for tolerance-mode batches of up to 4096 chains of a 4-age problem, the 16-lane form (fma only)
+pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + "," + (r"|sepaihrd_eval_quad_kernel" if arith_flag == "1" else ""))
 counters = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
     files = sorted(glob.glob(f"{src}/{d}/*/*counter_collection.csv"), key=os.path.getmtime)

@@ -11,7 +11,8 @@ for solver, name in ((0, "dopri5"), (1, "cashkarp")):
     pb = mm.workloads.build("c1", os.path.join(ROOT, "tests", "golden")).with_(arith=mm.ARITH_FMA, solver=solver, constraint_mode=1)
     hip = mm.HipObjective(pb)
     base = mm.draws.jitter_draws(pb, 1, 4096)
-    for B in (16, 256, 1024, 4096, 16384, 65536, 262144):
+    sizes = [int(v) for v in os.environ.get("SWEEP_SIZES", "16,256,1024,4096,16384,65536,262144").split(",")]
+    for B in sizes:
         theta = np.tile(base, ((B + 4095) // 4096, 1))[:B]
         d_t = torch.from_numpy(theta).cuda()
         d_l = torch.empty(B, dtype=torch.float64, device="cuda")
