@@ -5,7 +5,7 @@
 #include <cstdio>
 
 #define REP8(x) x x x x x x x x
-enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_FMA64_SGPR, OP_FMA32, OP_MOV32, OP_MIX, OP_MAX64, OP_DPP_MOV };
+enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_FMA64_SGPR, OP_FMA32, OP_MOV32, OP_MIX, OP_MAX64, OP_DPP_MOV, OP_FMA64_DEP1, OP_FMA64_DEP2, OP_FMA64_DEP3, OP_FMAC_DPP64 };
 
 template <int OP>
 __global__ void k(double* out, int iters, long long* ticks) {
@@ -52,6 +52,22 @@ __global__ void k(double* out, int iters, long long* ticks) {
 #define F(a, b) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b));
             F(f0, f1) F(f1, f2) F(f2, f3) F(f3, f4) F(f4, f5) F(f5, f6) F(f6, f7) F(f7, fm)
 #undef F
+        } else if (OP == OP_FMA64_DEP1) {  // one dependent chain: the result latency, not the issue interval
+#define F(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
+            F(a0) F(a0) F(a0) F(a0) F(a0) F(a0) F(a0) F(a0)
+#undef F
+        } else if (OP == OP_FMA64_DEP2) {
+#define F(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
+            F(a0) F(a1) F(a0) F(a1) F(a0) F(a1) F(a0) F(a1)
+#undef F
+        } else if (OP == OP_FMA64_DEP3) {
+#define F(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
+            F(a0) F(a1) F(a2) F(a0) F(a1) F(a2) F(a0) F(a1)
+#undef F
+        } else if (OP == OP_FMAC_DPP64) {  // v_fmac_f64 with a row_newbcast source: same rate as a plain fmac?
+#define F(a) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(c));
+            F(a0) F(a1) F(a2) F(a3) F(a4) F(a5) F(a6) F(a7)
+#undef F
         } else if (OP == OP_MIX) {
             // alternate FP64 fma and 32-bit moves: does a 32-bit op hide behind an FP64 op?
 #define F(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
@@ -89,5 +105,7 @@ int main() {
     run<OP_FMA64>("fma64", out); run<OP_MUL64>("mul64", out); run<OP_ADD64>("add64", out); run<OP_MAX64>("max64", out);
     run<OP_FMA64_SGPR>("fma64_sgpr", out); run<OP_FMA32>("fma32", out); run<OP_MOV32>("mov32", out);
     run<OP_DPP_MOV>("mov32_dpp", out); run<OP_MIX>("fma64+mov32", out);
+    run<OP_FMA64_DEP1>("fma64_dep1", out); run<OP_FMA64_DEP2>("fma64_dep2", out); run<OP_FMA64_DEP3>("fma64_dep3", out);
+    run<OP_FMAC_DPP64>("fmac64_dpp", out);
     return 0;
 }
