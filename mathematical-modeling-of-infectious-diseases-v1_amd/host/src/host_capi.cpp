@@ -6,6 +6,7 @@
 #include "epidemic_hip/BatchedHillClimbing.hpp"
 #include "epidemic_hip/BatchedParticleSwarm.hpp"
 #include "epidemic_hip/HipModelCalibrator.hpp"
+#include "epidemic_hip/HipNUTSSampler.hpp"
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
 #include "sepaihrd_hip.h"
@@ -441,6 +442,51 @@ int host_gradient(void* hv, const sepaihrd_problem* pb, int device, const double
     } catch (const std::exception& e) {
         g_error = e.what();
         return 1;
+    }
+}
+
+// HipNUTSSampler over a HipSEPAIHRDGradientObjectiveFunction built on the handle's parameter manager / data
+// (SEPAIHRDModelCalibration::runNUTS runs it as phase 2: MCMC_REFLECT).  Outputs as oracle_nuts; returns the number
+// of samples, or -1 on an exception (message in host_last_error).
+int host_nuts_run(void* hv, const sepaihrd_problem* pb, int device, int iterations, int adaptation_window, double delta_target,
+                  int max_tree_depth, double fd_epsilon, int constraint_mode, const double* theta0, uint32_t seed,
+                  double* samples, double* values, double* eps_trace, int32_t* depth_trace, double* best, double* best_value,
+                  long* gradient_calls, long* gradient_launches) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int n = pb->n_age;
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        h->pm->setConstraintMode(constraint_mode == 0 ? ConstraintMode::OPTIMIZATION_CLAMP : ConstraintMode::MCMC_REFLECT);
+        std::shared_ptr<IOdeSolverStrategy> solver;
+        if (pb->solver == SEPAIHRD_SOLVER_CASH_KARP54) solver = std::make_shared<CashKarpSolverStrategy>();
+        else solver = std::make_shared<Dopri5SolverStrategy>();
+        SimulationCache cache(1000);
+        HipSEPAIHRDGradientObjectiveFunction obj(*h->pm, cache, *h->data, std::vector<double>(pb->times, pb->times + pb->n_times),
+                                                 vec(pb->initial_state, 11 * n), solver, pb->abs_err, pb->rel_err, device,
+                                                 pb->arith == SEPAIHRD_ARITH_FMA);
+        obj.epsilon_ = fd_epsilon;
+        HipNUTSSampler nuts;
+        nuts.configure({{"nuts_iterations", double(iterations)}, {"nuts_adaptation_window", double(adaptation_window)},
+                        {"nuts_delta_target", delta_target}, {"nuts_max_tree_depth", double(max_tree_depth)},
+                        {"seed", double(seed)}});
+        IObjectiveFunction& iface = static_cast<HipSEPAIHRDObjectiveFunction&>(obj);
+        const OptimizationResult r = nuts.optimize(vec(theta0, P), iface, *h->pm);
+        const int ns = static_cast<int>(r.samples.size());
+        for (int s = 0; s < ns; ++s) {
+            for (int i = 0; i < P; ++i) samples[static_cast<size_t>(s) * P + i] = r.samples[static_cast<size_t>(s)][i];
+            values[s] = r.sampleObjectiveValues[static_cast<size_t>(s)];
+            eps_trace[s] = nuts.epsilonTrace()[static_cast<size_t>(s)];
+            depth_trace[s] = nuts.depthTrace()[static_cast<size_t>(s)];
+        }
+        if (r.bestParameters.size() == P)
+            for (int i = 0; i < P; ++i) best[i] = r.bestParameters[i];
+        *best_value = r.bestObjectiveValue;
+        if (gradient_calls) *gradient_calls = nuts.gradientCalls();
+        if (gradient_launches) *gradient_launches = nuts.gradientLaunches();
+        return ns;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
     }
 }
 

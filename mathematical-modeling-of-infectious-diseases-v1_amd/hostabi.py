@@ -46,6 +46,8 @@ def load_library() -> C.CDLL:
     lib.host_hc_run.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_calibrate_pso.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.host_nuts_run.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                  C.c_double, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.host_pso_run.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.host_ensemble.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_int, C.c_int, C.c_uint32,
                                   vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -127,6 +129,27 @@ class HostObjective:
         if rc != 0:
             raise RuntimeError("host_gradient: " + self.lib.host_last_error().decode())
         return v.value, g
+
+    def nuts(self, theta0, seed: int, iterations: int, adaptation_window: int, max_tree_depth: int = 10,
+             delta_target: float = 0.8, fd_epsilon: float = 1e-4, constraint_mode: int = 1, device: int = -1) -> dict:
+        """HipNUTSSampler::optimize over a HipSEPAIHRDGradientObjectiveFunction (SEPAIHRDModelCalibration::runNUTS)."""
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        keep: list = []
+        st = hipabi.build_problem_struct(self.pb, keep)
+        samples = np.empty((iterations, self.P))
+        values, eps = np.empty(iterations), np.empty(iterations)
+        depth = np.empty(iterations, dtype=np.int32)
+        best = np.empty(self.P)
+        bv = C.c_double(0.0)
+        nc, nl = C.c_long(0), C.c_long(0)
+        ns = self.lib.host_nuts_run(self.h, C.byref(st), device, iterations, adaptation_window, delta_target,
+                                    max_tree_depth, fd_epsilon, constraint_mode, th.ctypes.data, seed,
+                                    samples.ctypes.data, values.ctypes.data, eps.ctypes.data, depth.ctypes.data,
+                                    best.ctypes.data, C.byref(bv), C.byref(nc), C.byref(nl))
+        if ns < 0:
+            raise RuntimeError("host_nuts_run: " + self.lib.host_last_error().decode())
+        return {"samples": samples[:ns], "sample_values": values[:ns], "epsilon_trace": eps[:ns], "depth_trace": depth[:ns],
+                "best": best, "best_value": bv.value, "gradient_calls": nc.value, "gradient_launches": nl.value}
 
     def calibrate(self, hc_seed: int, mh_seed: int, hc_iterations: int, mh_iterations: int, burn_in: int,
                   cloud_size_multiplier: int = 8, threads: int = 16, adaptation_period: int = 100, thinning: int = 1,

@@ -296,6 +296,44 @@ int oracle_gradient(void* hv, const double* theta, double epsilon, double* value
     return 0;
 }
 
+// NUTSSampler restated over the finite-difference gradient objective (constraint mode as given: the reference
+// runs it as phase 2, MCMC_REFLECT).  samples [iterations][P], values / eps_trace [iterations], depth_trace
+// [iterations]; returns the number of samples stored, or -2 when an integration throws.
+int oracle_nuts(void* hv, int iterations, int adaptation_window, double delta_target, int max_tree_depth, double fd_epsilon,
+                int constraint_mode, const double* theta0, uint32_t seed, double* samples, double* values,
+                double* eps_trace, int32_t* depth_trace, double* best, double* best_value, long* gradient_calls) {
+    auto* h = static_cast<Handle*>(hv);
+    oracle::Problem pb = h->pb;
+    pb.pm.mode = constraint_mode == 0 ? oracle::OPTIMIZATION_CLAMP : oracle::MCMC_REFLECT;
+    const int P = static_cast<int>(pb.pm.names.size());
+    oracle::NUTSSettings cfg;
+    cfg.iterations = iterations; cfg.adaptation_window = adaptation_window; cfg.delta_target = delta_target;
+    cfg.max_tree_depth = max_tree_depth;
+    auto grad_fn = [&](const std::vector<double>& th, std::vector<double>& g) {
+        return oracle::evaluate_with_gradient(pb, th, g, fd_epsilon);
+    };
+    auto fn = [&](const std::vector<double>& th) {
+        oracle::EvalInfo info;
+        const double v = oracle::objective(pb, th, &info);
+        if (info.status >= 2) throw std::runtime_error("SimulationException");
+        return v;
+    };
+    try {
+        const oracle::NUTSResult r = oracle::nuts(cfg, std::vector<double>(theta0, theta0 + P), grad_fn, fn, pb.pm, seed);
+        const int ns = static_cast<int>(r.samples.size());
+        for (int s = 0; s < ns; ++s) {
+            std::copy(r.samples[s].begin(), r.samples[s].end(), samples + static_cast<size_t>(s) * P);
+            values[s] = r.sample_values[s];
+            eps_trace[s] = r.epsilon_trace[s];
+            depth_trace[s] = r.depth_trace[s];
+        }
+        if (!r.best.empty()) std::copy(r.best.begin(), r.best.end(), best);
+        *best_value = r.best_value;
+        if (gradient_calls) *gradient_calls = r.gradient_calls;
+        return ns;
+    } catch (const std::exception&) { return -2; }
+}
+
 int oracle_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,
                      int mh_iterations, int burn_in, int adaptation_period, int thinning, uint32_t mh_seed,
                      const double* x0, double* best, double* best_value, double* initial_value,

@@ -63,6 +63,10 @@ int oracle_pso(void *h, const double *cfg, const double *x0, uint32_t seed, doub
                double *final_cov, double *trace, long *evaluations);
 /* SEPAIHRDGradientObjectiveFunction::evaluate_with_gradient restated; returns 0, or 2 when an integration throws */
 int oracle_gradient(void *h, const double *theta, double epsilon, double *value, double *grad);
+/* NUTSSampler restated (seeded) over the finite-difference gradient objective; returns the number of samples or -2 */
+int oracle_nuts(void *h, int iterations, int adaptation_window, double delta_target, int max_tree_depth, double fd_epsilon,
+                int constraint_mode, const double *theta0, uint32_t seed, double *samples, double *values,
+                double *eps_trace, int32_t *depth_trace, double *best, double *best_value, long *gradient_calls);
 /* ModelCalibrator restated: HC phase (clamp) -> covariance conditioning -> one MH chain (reflect).
  * samples capacity: (mh_iterations / thinning + 1) x P.  All outputs nullable except best/best_value. */
 int oracle_calibrate(void *h, int hc_iterations, int cloud_size_multiplier, int threads, uint32_t hc_seed,

@@ -72,6 +72,8 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.oracle_pso.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.oracle_gradient.argtypes = [vp, vp, C.c_double, vp, vp]
+    lib.oracle_nuts.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, vp, C.c_uint32, vp, vp, vp, vp,
+                                vp, vp, vp]
     lib.oracle_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.oracle_condition_covariance.argtypes = [vp, vp, vp]
@@ -228,6 +230,24 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("SimulationException")
         return v.value, g
+
+    def nuts(self, theta0, seed: int, iterations: int, adaptation_window: int, max_tree_depth: int = 10,
+             delta_target: float = 0.8, fd_epsilon: float = 1e-4, constraint_mode: int = 1) -> dict:
+        """NUTSSampler restated over the finite-difference gradient objective."""
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        samples = np.empty((iterations, self.P))
+        values, eps = np.empty(iterations), np.empty(iterations)
+        depth = np.empty(iterations, dtype=np.int32)
+        best = np.empty(self.P)
+        bv = C.c_double(0.0)
+        ng = C.c_long(0)
+        ns = self.lib.oracle_nuts(self.h, iterations, adaptation_window, delta_target, max_tree_depth, fd_epsilon,
+                                  constraint_mode, th.ctypes.data, seed, samples.ctypes.data, values.ctypes.data,
+                                  eps.ctypes.data, depth.ctypes.data, best.ctypes.data, C.byref(bv), C.byref(ng))
+        if ns < 0:
+            raise RuntimeError("SimulationException")
+        return {"samples": samples[:ns], "sample_values": values[:ns], "epsilon_trace": eps[:ns], "depth_trace": depth[:ns],
+                "best": best, "best_value": bv.value, "gradient_calls": ng.value}
 
     def model_parameters(self, theta) -> dict:
         """Model fields after updateModelParameters(theta) (SEPAIHRDParameterManager.cpp:164-287)."""

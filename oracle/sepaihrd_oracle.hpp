@@ -1810,6 +1810,204 @@ inline PSOResult particle_swarm(const PSOSettings& cfg, const std::vector<double
 }
 
 // -----------------------------------------------------------------------------
+// NUTSSampler (src/model/optimizers/NUTSSampler.cpp:41-428, include/model/optimizers/NUTSSampler.hpp): the
+// single-phase No-U-Turn sampler over the finite-difference gradient objective -- heuristic initial step size
+// (:230-287), leapfrog with the gradient norm clipped at 1000 (:290-318), recursive tree doubling (Hoffman & Gelman
+// 2014, algorithm 6, :321-406), U-turn test (:409-422), dual averaging inside the adaptation window (:166-183).
+// Every gradient the reference evaluates is evaluated here, in its order: THREE per tree leaf (two in the leapfrog,
+// one more at the leaf's end point), `gradient_calls` counts them.  Random draws in the reference's order: a fresh
+// distribution object per draw site (normal for the momentum, exponential for the slice, uniform_int for the
+// direction, uniform_real for the subtree choices).  The reference seeds from std::random_device (:21); here a seed.
+// Eigen's norm() / dot() are restated as plain left-to-right sums (their vectorised order is not pinned).
+// -----------------------------------------------------------------------------
+struct NUTSSettings {
+    int iterations = 2000, adaptation_window = 500, max_tree_depth = 10;
+    double delta_target = 0.8;
+};
+struct NUTSResult {
+    std::vector<std::vector<double>> samples;
+    std::vector<double> sample_values, epsilon_trace;
+    std::vector<int> depth_trace;
+    std::vector<double> best;
+    double best_value = -std::numeric_limits<double>::infinity();
+    long gradient_calls = 0;
+};
+using GradObjective = std::function<double(const std::vector<double>&, std::vector<double>&)>;
+
+inline NUTSResult nuts(const NUTSSettings& cfg, const std::vector<double>& theta0, const GradObjective& grad_fn,
+                       const Objective& objective_fn, const ParameterManager& pm, uint32_t seed) {
+    const int P = static_cast<int>(theta0.size());
+    using Vec = std::vector<double>;
+    NUTSResult out;
+    std::mt19937 rng(seed);
+    constexpr double DELTA_MAX = 1000.0, MAX_GRAD_NORM = 1000.0;
+    auto dot = [&](const Vec& a, const Vec& b) { double s = 0.0; for (int i = 0; i < P; ++i) s += a[i] * b[i]; return s; };
+    auto gradient = [&](const Vec& th, Vec& g) { ++out.gradient_calls; g.assign(P, 0.0); return grad_fn(th, g); };
+    auto clip = [&](Vec& g) {
+        const double nrm = std::sqrt(dot(g, g));
+        if (nrm > MAX_GRAD_NORM) for (double& v : g) v *= MAX_GRAD_NORM / nrm;
+        return nrm;
+    };
+    auto leapfrog = [&](Vec& th, Vec& r, double eps) {  // :290-318
+        Vec g;
+        gradient(th, g); clip(g);
+        for (int i = 0; i < P; ++i) r[i] += 0.5 * eps * g[i];
+        for (int i = 0; i < P; ++i) th[i] += eps * r[i];
+        th = pm.applyConstraints(th);
+        gradient(th, g); clip(g);
+        for (int i = 0; i < P; ++i) r[i] += 0.5 * eps * g[i];
+    };
+    auto no_uturn = [&](const Vec& tm, const Vec& tp, const Vec& rm, const Vec& rp) {  // :409-422
+        double dm = 0.0, dp = 0.0;
+        for (int i = 0; i < P; ++i) { dm += (tp[i] - tm[i]) * rm[i]; dp += (tp[i] - tm[i]) * rp[i]; }
+        return dm >= 0 && dp >= 0;
+    };
+    struct Tree { Vec theta_minus, theta_plus, r_minus, r_plus, theta_prime; int n_valid = 0; bool s = false; double alpha = 0.0; int n_alpha = 0; };
+    std::function<void(const Vec&, const Vec&, double, int, int, double, double, Tree&)> build =
+        [&](const Vec& th, const Vec& r, double log_u, int v, int j, double eps, double H0, Tree& tree) {  // :321-406
+            if (j == 0) {
+                Vec tp = th, rp = r, g;
+                leapfrog(tp, rp, v * eps);
+                const double log_p = gradient(tp, g);
+                const double Hp = log_p - 0.5 * dot(rp, rp);
+                tree.n_valid = (log_u <= Hp) ? 1 : 0;
+                tree.s = (log_u < Hp + DELTA_MAX);
+                tree.theta_minus = tree.theta_plus = tree.theta_prime = tp;
+                tree.r_minus = tree.r_plus = rp;
+                tree.alpha = std::min(1.0, std::exp(Hp - H0));
+                tree.n_alpha = 1;
+                return;
+            }
+            Tree left;
+            build(th, r, log_u, v, j - 1, eps, H0, left);
+            if (!left.s) { tree = left; return; }
+            Tree right;
+            if (v == -1) {
+                build(left.theta_minus, left.r_minus, log_u, v, j - 1, eps, H0, right);
+                tree.theta_minus = right.theta_minus; tree.r_minus = right.r_minus;
+                tree.theta_plus = left.theta_plus; tree.r_plus = left.r_plus;
+            } else {
+                build(left.theta_plus, left.r_plus, log_u, v, j - 1, eps, H0, right);
+                tree.theta_minus = left.theta_minus; tree.r_minus = left.r_minus;
+                tree.theta_plus = right.theta_plus; tree.r_plus = right.r_plus;
+            }
+            if (right.s) {
+                tree.n_valid = left.n_valid + right.n_valid;
+                const double prob = tree.n_valid > 0 ? static_cast<double>(right.n_valid) / static_cast<double>(tree.n_valid) : 0.0;
+                tree.theta_prime = (std::uniform_real_distribution<>(0.0, 1.0)(rng) < prob) ? right.theta_prime : left.theta_prime;
+                tree.alpha = left.alpha + right.alpha;
+                tree.n_alpha = left.n_alpha + right.n_alpha;
+                tree.s = left.s && right.s && no_uturn(tree.theta_minus, tree.theta_plus, tree.r_minus, tree.r_plus);
+            } else {
+                tree.theta_prime = left.theta_prime;
+                tree.n_valid = left.n_valid;
+                tree.s = false;
+                tree.alpha = left.alpha;
+                tree.n_alpha = left.n_alpha;
+            }
+        };
+
+    // ---- findReasonableEpsilon :230-287
+    double epsilon;
+    {
+        double avg = 0.0;
+        for (int i = 0; i < P; ++i) avg += pm.sigmas.at(pm.names[i]);
+        avg /= P;
+        epsilon = std::max(1e-6, std::min(avg * 0.1, 0.1));
+        std::normal_distribution<> normal(0.0, 1.0);
+        Vec r(P), g;
+        for (int i = 0; i < P; ++i) r[i] = normal(rng);
+        const double log_p = gradient(theta0, g);
+        if (std::isfinite(log_p)) {
+            const double H0 = log_p - 0.5 * dot(r, r);
+            Vec tp = theta0, rp = r;
+            leapfrog(tp, rp, epsilon);
+            double lpp = gradient(tp, g);
+            double Hp = lpp - 0.5 * dot(rp, rp);
+            double accept_prob = std::exp(std::min(0.0, Hp - H0));
+            for (int iter = 0; iter < 5; ++iter) {
+                if (accept_prob < 0.1 && epsilon > 1e-8) epsilon *= 0.5;
+                else if (accept_prob > 0.9 && epsilon < 1.0) epsilon *= 1.5;
+                else break;
+                tp = theta0; rp = r;
+                leapfrog(tp, rp, epsilon);
+                lpp = gradient(tp, g);
+                if (!std::isfinite(lpp)) { epsilon *= 0.5; continue; }
+                Hp = lpp - 0.5 * dot(rp, rp);
+                accept_prob = std::exp(std::min(0.0, Hp - H0));
+            }
+        }
+    }
+    const double mu = std::log(10.0 * epsilon);
+    double epsilon_bar = epsilon, H_bar = 0.0;
+    const double gamma = 0.05, t0 = 10.0, kappa = 0.75;
+    Vec theta_m = theta0;
+    for (int m = 1; m <= cfg.iterations; ++m) {  // :72-214
+        std::normal_distribution<> normal(0.0, 1.0);
+        Vec r0(P), g;
+        for (int i = 0; i < P; ++i) r0[i] = normal(rng);
+        const double log_p = gradient(theta_m, g);
+        clip(g);
+        if (!std::isfinite(log_p)) {
+            if (!out.samples.empty()) {
+                out.samples.push_back(out.samples.back());
+                out.sample_values.push_back(out.sample_values.back());
+                out.epsilon_trace.push_back(epsilon);
+                out.depth_trace.push_back(-1);
+            }
+            continue;
+        }
+        const double H0 = log_p - 0.5 * dot(r0, r0);
+        const double log_u = H0 - std::exponential_distribution<>(1.0)(rng);
+        Vec theta_minus = theta_m, theta_plus = theta_m, r_minus = r0, r_plus = r0, theta_next = theta_m;
+        int j = 0, n = 1, n_alpha = 0;
+        bool s = true;
+        double alpha = 0.0;
+        while (s && j < cfg.max_tree_depth) {
+            const int v = (std::uniform_int_distribution<>(0, 1)(rng) * 2) - 1;
+            Tree sub;
+            if (v == -1) {
+                build(theta_minus, r_minus, log_u, v, j, epsilon, H0, sub);
+                theta_minus = sub.theta_minus; r_minus = sub.r_minus;
+            } else {
+                build(theta_plus, r_plus, log_u, v, j, epsilon, H0, sub);
+                theta_plus = sub.theta_plus; r_plus = sub.r_plus;
+            }
+            if (sub.s && no_uturn(theta_minus, theta_plus, r_minus, r_plus)) {
+                const double acceptance = static_cast<double>(sub.n_valid) / static_cast<double>(n + sub.n_valid);
+                if (std::uniform_real_distribution<>(0.0, 1.0)(rng) < acceptance) theta_next = sub.theta_prime;
+                n += sub.n_valid;
+                alpha += sub.alpha;
+                n_alpha += sub.n_alpha;
+                j++;
+            } else {
+                s = false;
+            }
+        }
+        theta_m = theta_next;
+        if (m <= cfg.adaptation_window) {  // :166-183
+            const double avg_alpha = n_alpha > 0 ? alpha / n_alpha : 0.0;
+            const double eta = 1.0 / (m + t0);
+            H_bar = (1.0 - eta) * H_bar + eta * (cfg.delta_target - avg_alpha);
+            const double log_eps = mu - (std::sqrt(m) / gamma) * H_bar;
+            epsilon = std::exp(log_eps);
+            const double m_kappa = std::pow(m, -kappa);
+            epsilon_bar = std::exp(m_kappa * log_eps + (1.0 - m_kappa) * std::log(epsilon_bar));
+        } else {
+            epsilon = epsilon_bar;
+        }
+        const Vec constrained = pm.applyConstraints(theta_m);
+        out.samples.push_back(constrained);
+        const double value = objective_fn(constrained);
+        out.sample_values.push_back(value);
+        out.epsilon_trace.push_back(epsilon);
+        out.depth_trace.push_back(j);
+        if (value > out.best_value) { out.best_value = value; out.best = constrained; }
+    }
+    return out;
+}
+
+// -----------------------------------------------------------------------------
 // BASELINE config 0 ("plumbing", CPU only): the age-structured SIR model behind the same interfaces,
 // AgeSIRModel::computeDerivatives (src/sir_age_structured/AgeSIRModel.cpp:106-139):
 //   lambda = q (C_current (I / N)) with I/N = 0 where N <= 1e-9, clipped at 0; dS = -lambda S,

@@ -233,6 +233,26 @@ def test_finite_difference_gradient_objective(mm, oracle_py, ref_fixture):
     assert np.isclose((o.calculate(tp) - o.calculate(theta)) / h, ref_g[k], rtol=1e-6)
 
 
+def test_no_u_turn_sampler_follows_the_reference_flow(mm, oracle_py, ref_fixture):
+    """HipNUTSSampler against the restatement of NUTSSampler.cpp:41-428 over the finite-difference gradient
+    objective, same seed: same tree depths, step sizes, samples and values.  The repeated parameter vectors the
+    reference evaluates again (three gradient calls per leaf) are served from the last evaluations: the
+    reference's call count with about a third of the launches."""
+    pb = _multiplier_fixture(mm, ref_fixture)
+    theta = np.concatenate([np.asarray(ref_fixture.base_theta), [1.0, 0.8]])
+    pb = pb.with_(base_theta=theta, constraint_mode=1)
+    kw = dict(iterations=10, adaptation_window=4, max_tree_depth=3)
+    ref = oracle_py.Oracle(pb).nuts(theta, 3, **kw)
+    got = mm.HostObjective(pb).nuts(theta, 3, **kw)
+    assert np.array_equal(got["depth_trace"], ref["depth_trace"]) and ref["depth_trace"].max() >= 2
+    np.testing.assert_allclose(got["epsilon_trace"], ref["epsilon_trace"], rtol=1e-6)
+    np.testing.assert_allclose(got["samples"], ref["samples"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got["sample_values"], ref["sample_values"], rtol=1e-6)
+    assert got["gradient_calls"] == ref["gradient_calls"]
+    assert got["gradient_launches"] <= 0.45 * got["gradient_calls"]
+    assert got["best_value"] == got["sample_values"].max()
+
+
 def test_finite_difference_gradient_row_mismatch_follows_the_reference(mm, oracle_py, shipped):
     """With run-up output rows the reference's perturbed likelihood fails its dimension check:
     every entry is (lowest() - f) / eps (here -inf), no simulation is needed for it."""

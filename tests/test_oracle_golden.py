@@ -253,3 +253,36 @@ def test_particle_swarm_restatement_properties(oracle_py, shipped):
     # opposition learning re-evaluates the selected swarm once
     o = orc.particle_swarm(shipped.base_theta, 5, use_opposition_learning=1, **kw)
     assert o["evaluations"] == 8 * 8
+
+
+def _nuts_fixture(mm, ref_fixture):
+    names = list(ref_fixture.param_names) + ["E0_multiplier", "I0_multiplier"]
+    sig = dict(ref_fixture.sigmas); sig.update(E0_multiplier=0.05, I0_multiplier=0.05)
+    bnd = dict(ref_fixture.bounds); bnd.update(E0_multiplier=(0.5, 1.2), I0_multiplier=(0.1, 3.0))
+    theta = np.concatenate([np.asarray(ref_fixture.base_theta), [1.0, 0.8]])
+    return ref_fixture.with_(param_names=names, sigmas=sig, bounds=bnd, base_theta=theta, arith=mm.ARITH_STRICT,
+                             constraint_mode=1)
+
+
+def test_nuts_restatement_properties(mm, oracle_py, ref_fixture):
+    """oracle::nuts (NUTSSampler.cpp:41-428): determinism, bookkeeping of the reference's gradient calls (three per
+    tree leaf + one per iteration + the step-size search), dual averaging only inside the adaptation window, samples
+    inside the bounds, best value = max of the stored values."""
+    pb = _nuts_fixture(mm, ref_fixture)
+    orc = oracle_py.Oracle(pb)
+    kw = dict(iterations=10, adaptation_window=4, max_tree_depth=3)
+    a = orc.nuts(pb.base_theta, 3, **kw)
+    b = orc.nuts(pb.base_theta, 3, **kw)
+    c = orc.nuts(pb.base_theta, 4, **kw)
+    assert np.array_equal(a["samples"], b["samples"]) and not np.array_equal(a["samples"], c["samples"])
+    assert len(a["samples"]) == 10 and np.all((a["depth_trace"] >= 0) & (a["depth_trace"] <= 3))
+    assert np.all(a["epsilon_trace"][4:] == a["epsilon_trace"][4]) and len(set(a["epsilon_trace"][:4])) == 4
+    lo, hi, _ = pb.bounds_arrays()
+    assert np.all(a["samples"] >= lo) and np.all(a["samples"] <= hi)
+    assert a["best_value"] == a["sample_values"].max() and np.any(np.diff(a["sample_values"]) != 0)
+    # a tree of depth j that runs to completion has 2^j leaves; the main loop doubles j = 0, 1, ... so an iteration
+    # that reached depth d evaluated at most 2^(d+1) - 1 leaves (one more subtree may have been built and refused)
+    leaves_max = sum(2 ** (int(d) + 1) - 1 + 2 ** (int(d) + 1) for d in a["depth_trace"])
+    assert 10 + 3 <= a["gradient_calls"] <= 10 + 3 * leaves_max + 3 * 6 + 1
+    # the stored value is the objective at the stored (constrained) sample
+    np.testing.assert_allclose(a["sample_values"][-1], orc.calculate(a["samples"][-1]), rtol=1e-12)
