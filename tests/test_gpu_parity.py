@@ -185,6 +185,33 @@ def test_other_age_class_counts(mm, oracle_py, shipped, n_age, solver):
     np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("n_age", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_other_age_class_counts_tolerance_arithmetic(mm, oracle_py, shipped, n_age, solver):
+    """The same layouts in the production (fma) arithmetic, which has its own code paths there: n = 3 runs the
+    16-lanes-per-chain small-batch kernel with a padded age class, n = 8 and 16 form the contact sum with
+    v_fmac_f64_dpp row broadcasts (bank-masked for two 8-lane chains per row).  North-star bar 1e-6 relative on the
+    states; measured ~1e-11."""
+    from mmid_amd import draws
+    if n_age <= 3:
+        pb = mm.restrict_age_classes(shipped, list(range(n_age)))
+    else:
+        pb = mm.widen_age_classes(shipped, n_age // 4)
+    pb.solver = solver
+    pb.arith = mm.ARITH_FMA
+    pb.times = pb.times[:120]
+    pb = pb.with_(obs_H=pb.obs_H[:100], obs_ICU=pb.obs_ICU[:100], obs_D=pb.obs_D[:100])
+    B = 19
+    theta = draws.jitter_draws(pb, 3, B)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"]) and np.all(ref["status"] == 0)
+    same = (got["n_accept"] == ref["n_accept"]) & (got["n_reject"] == ref["n_reject"])
+    assert same.mean() >= 0.9
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-8
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-8)
+
+
 @pytest.mark.parametrize("arith", ["strict", "fma"])
 @pytest.mark.parametrize("solver,B", [(0, 20000), (0, 32768 + 37), (1, 20000), (1, 32768 + 37)])
 def test_saturating_batches_use_the_same_arithmetic(mm, oracle_py, synth400, draws, solver, B, arith):
