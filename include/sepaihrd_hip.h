@@ -296,8 +296,8 @@ typedef struct sepaihrd_kernel_info {
     char device_name[128];
 } sepaihrd_kernel_info;
 int sepaihrd_get_kernel_info(sepaihrd_ctx *ctx, sepaihrd_kernel_info *info);
-/* The same report for a launch of `batch_chains` chains: the tolerance-mode build integrates batches of up to 4096
- * chains of a 4-age problem with sixteen lanes per chain (a quad of lanes per age class) instead of four, so that a
+/* The same report for a launch of `batch_chains` chains: batches of up to 4096
+ * chains of a 4-age problem are integrated with sixteen lanes per chain (a quad of lanes per age class) instead of four, so that a
  * batch too small to fill the chip still spreads over four times as many SIMDs.  Results are bit-identical between
  * the two forms.  batch_chains <= 0: the large-batch kernel (what sepaihrd_get_kernel_info reports). */
 int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx *ctx, int32_t batch_chains, sepaihrd_kernel_info *info);

@@ -1082,6 +1082,10 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProbl
 }
 
 #if SEPAIHRD_ARITH_FMA
+#define SEP_QUAD_NAME "sepaihrd_eval_quad_kernel[fma]"
+#else
+#define SEP_QUAD_NAME "sepaihrd_eval_quad_kernel[strict]"
+#endif
 #include "sepaihrd_lane_split.inc"  // 16-lanes-per-chain form for small batches of the 4-age model
 
 // SEPAIHRD_LANE_SPLIT=0 keeps every launch on the 4-lane kernel, =1 uses the 16-lane form at any batch size
@@ -1093,7 +1097,6 @@ inline bool lane_split_wanted(int B) {
     }();
     return mode < 0 ? B <= QUAD_MAX_CHAINS : mode != 0;
 }
-#endif
 
 // ----------------------------------------------------------------------------------
 // launch plumbing
@@ -1125,11 +1128,9 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
-#if SEPAIHRD_ARITH_FMA
     if constexpr (LPC == 4) {
         if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
-#endif
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
     if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
@@ -1158,13 +1159,10 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
 
 template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
-#if SEPAIHRD_ARITH_FMA
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(batch))
-            return info_of(&sepaihrd_eval_quad_kernel<SOLVER>, pb, QUAD_LANES, info, "sepaihrd_eval_quad_kernel[fma]");
+            return info_of(&sepaihrd_eval_quad_kernel<SOLVER>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
     }
-#endif
-    (void)batch;
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name);
 }
 

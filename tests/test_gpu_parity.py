@@ -341,18 +341,19 @@ def test_minimal_problem_one_parameter_no_schedule(mm, oracle_py, ref_fixture):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["fma", "strict"])
 @pytest.mark.parametrize("problem,solver,chains", [("synth_400d_n4.json", 0, 1021), ("synth_400d_n4.json", 1, 1021),
                                                    ("shipped_problem.json", 0, 37)])
-def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains):
-    """Up to 4096 chains the tolerance-mode build runs the 16-lanes-per-chain form of the integrator
-    (csrc/sepaihrd_lane_split.inc); SEPAIHRD_LANE_SPLIT=0 keeps the 4-lane kernel.  Same chains through both, in
-    two processes (the switch is read once): log-likelihood, status, step counts and every trajectory state are the
-    same bits -- a chain's result does not depend on the batch it was evaluated in.  1021 and 37 chains leave a
-    ragged last wave in both layouts."""
+def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains, arith):
+    """Up to 4096 chains a 4-age problem runs the 16-lanes-per-chain form of the integrator
+    (csrc/sepaihrd_lane_split.inc), in both arithmetic builds; SEPAIHRD_LANE_SPLIT=0 keeps the 4-lane kernel.  Same
+    chains through both, in two processes (the switch is read once): log-likelihood, status, step counts and every
+    trajectory state are the same bits -- a chain's result does not depend on the batch it was evaluated in.
+    1021 and 37 chains leave a ragged last wave in both layouts."""
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "compare_lane_split.py")
-    r = subprocess.run([sys.executable, tool, "--problem", problem, "--solver", str(solver), "--chains", str(chains)],
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, tool, "--problem", problem, "--solver", str(solver), "--chains", str(chains),
+                        "--arith", arith], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "traj: identical=True" in r.stdout and "n_accept: identical=True" in r.stdout

@@ -10,7 +10,7 @@ def child(args):
     import mmid_amd_loader
     mm = mmid_amd_loader.load()
     pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", args.problem)).with_(
-        solver=args.solver, arith=mm.ARITH_FMA)
+        solver=args.solver, arith=mm.ARITH_FMA if args.arith == "fma" else mm.ARITH_STRICT)
     if args.one_step:
         times = np.array([0.0, args.one_step])
         pb = pb.with_(times=times, obs_H=pb.obs_H[:2], obs_ICU=pb.obs_ICU[:2], obs_D=pb.obs_D[:2])
@@ -25,6 +25,7 @@ if __name__ == "__main__":
     ap.add_argument("--chains", type=int, default=256)
     ap.add_argument("--out", default=None)
     ap.add_argument("--problem", default="synth_400d_n4.json")
+    ap.add_argument("--arith", choices=["fma", "strict"], default="fma")
     ap.add_argument("--one-step", type=float, default=0.0)
     a = ap.parse_args()
     if a.out:
@@ -34,7 +35,7 @@ if __name__ == "__main__":
     for mode in ("0", "1"):
         out = f"/tmp/lane_split_{mode}.npz"
         env = dict(os.environ, SEPAIHRD_LANE_SPLIT=mode)
-        subprocess.run([sys.executable, __file__, "--solver", str(a.solver), "--chains", str(a.chains), "--out", out, "--problem", a.problem,
+        subprocess.run([sys.executable, __file__, "--solver", str(a.solver), "--chains", str(a.chains), "--out", out, "--problem", a.problem, "--arith", a.arith,
                         "--one-step", str(a.one_step)],
                        env=env, check=True)
         outs.append(np.load(out))
