@@ -12,8 +12,12 @@
 //     the chain's parameters live in that lane's VGPRs -- HBM is touched once at the
 //     start (theta) and once at the end (log-likelihood, counters);
 //   * the only cross-lane traffic is the age-contact contraction
-//     lambda_i = sum_j M(i,j) pi_j (DPP quad broadcasts for n<=4, wave shuffles above),
-//     the max-norm of the RK error estimate and the per-day likelihood row sum;
+//     lambda_i = sum_j M(i,j) pi_j (DPP quad_perm broadcasts for n <= 4; for n = 8, 16 DPP row_newbcast, in the
+//     tolerance build fused into the multiply-add as v_fmac_f64_dpp), the max-norm of the RK error estimate and
+//     the per-day likelihood row sum;
+//   * batches of up to 4096 chains of a problem with n <= 4 run a second form of the integrator with SIXTEEN lanes
+//     per chain (sepaihrd_lane_split.inc: the compartments of an age class spread over a quad of lanes), so that a
+//     batch too small to fill the chip still puts a wave on every SIMD; bit-identical results;
 //   * step-size control is per chain: lanes of one chain always agree, chains of one
 //     wavefront may take different numbers of steps (the wave runs until its slowest
 //     chain is done);
