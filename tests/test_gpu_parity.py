@@ -357,3 +357,18 @@ def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains, arith):
                         "--arith", arith], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "traj: identical=True" in r.stdout and "n_accept: identical=True" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith,solver,seed", [("fma", 0, 7), ("fma", 1, 8), ("strict", 0, 9), ("strict", 1, 10)])
+def test_small_batch_kernel_fuzz(arith, solver, seed):
+    """The two forms of the integrator against each other on 24 random variants of the shipped problem: 3 or 4 age
+    classes (3 pads a lane), output grids of random length and stride, tolerances 1e-8 .. 1e-4, attempt budgets
+    that cut chains short (status 3), both constraint modes, draws beyond the bounds, 1 .. 69 chains.  Every output
+    array, trajectories included, must be the same bits."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "compare_lane_split.py")
+    r = subprocess.run([sys.executable, tool, "--problem", "shipped_problem.json", "--arith", arith, "--solver", str(solver),
+                        "--fuzz", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all arrays identical=True" in r.stdout, r.stdout + r.stderr
