@@ -176,6 +176,14 @@ int sepaihrd_eval_batch(sepaihrd_ctx *ctx, const double *theta, int B, double *l
                         int32_t *status, int32_t *n_accept, int32_t *n_reject, double *ll_parts,
                         double *traj);
 
+/* The same evaluation in two halves: begin uploads theta and launches on a stream of the context's own and returns
+ * at once; end waits and downloads (any output may be NULL; no trajectory output in this form).  One begin per
+ * context at a time.  For callers that hold several contexts and want their evaluations in flight together -- the
+ * finite-difference objective runs its centre value and its P perturbed simulations this way. */
+int sepaihrd_eval_batch_begin(sepaihrd_ctx *ctx, const double *theta, int B);
+int sepaihrd_eval_batch_end(sepaihrd_ctx *ctx, double *loglik, int32_t *status, int32_t *n_accept, int32_t *n_reject,
+                            double *ll_parts);
+
 /* Device-pointer form: same arguments but every pointer is a DEVICE pointer on ctx's device,
  * and the launches (integrator kernel + two likelihood-pass kernels) are asynchronous on `stream`
  * (a hipStream_t, NULL = default stream).  No synchronisation.  The ctx-owned workspace

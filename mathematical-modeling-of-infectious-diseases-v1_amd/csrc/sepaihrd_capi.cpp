@@ -37,6 +37,8 @@ struct sepaihrd_ctx {
     std::string last_error;
     // staging buffers for the host-pointer entry point (grown on demand)
     size_t cap_B = 0;
+    hipStream_t own_stream = nullptr;  // sepaihrd_eval_batch_begin / _end
+    int pending_B = 0;
     bool cap_traj = false;
     double* d_theta = nullptr;
     double* d_loglik = nullptr;
@@ -370,6 +372,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
 void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     free_staging(ctx);
     free_workspace(ctx);
     for (void* p : ctx->ens_buf)
@@ -486,6 +489,7 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
     if (B == 0) return SEPAIHRD_OK;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const size_t traj_elems = traj ? (size_t)B * ctx->T * NUM_COMP * ctx->n : 0;
+    if (ctx->pending_B > 0) { ctx->last_error = "eval_batch: a sepaihrd_eval_batch_begin is pending"; return SEPAIHRD_E_INVALID_ARG; }
     if ((size_t)B > ctx->cap_B) {
         const size_t keep_traj = ctx->cap_traj_elems;
         double* keep = ctx->d_traj;
@@ -531,6 +535,56 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
     if (traj)
         HIP_TRY(hipMemcpy(traj, ctx->d_traj, traj_elems * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+// The host-pointer evaluation in two halves on a stream of the context's own, so that a caller with two contexts
+// (the finite-difference objective: centre value and perturbed batch) has both in flight at once.
+int sepaihrd_eval_batch_begin(sepaihrd_ctx* ctx, const double* theta, int B) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    if (B <= 0 || !theta) { ctx->last_error = "eval_batch_begin: NULL theta or B <= 0"; return SEPAIHRD_E_INVALID_ARG; }
+    if (ctx->pending_B > 0) { ctx->last_error = "eval_batch_begin: the previous begin has no end yet"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (!ctx->own_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), ctx, return SEPAIHRD_E_HIP);
+    if ((size_t)B > ctx->cap_B) {
+        const size_t keep_traj = ctx->cap_traj_elems;
+        double* keep = ctx->d_traj;
+        ctx->d_traj = nullptr;
+        free_staging(ctx);
+        ctx->d_traj = keep;
+        ctx->cap_traj_elems = keep_traj;
+        HIP_TRY(hipMalloc((void**)&ctx->d_theta, (size_t)B * ctx->P * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_loglik, (size_t)B * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_status, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_nacc, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_nrej, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc((void**)&ctx->d_parts, (size_t)B * 3 * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        ctx->cap_B = (size_t)B;
+    }
+    if (sepaihrd_reserve(ctx, B) != SEPAIHRD_OK) return SEPAIHRD_E_HIP;  // workspace growth is not stream-ordered
+    HIP_TRY(hipMemcpyAsync(ctx->d_theta, theta, (size_t)B * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->own_stream), ctx,
+            return SEPAIHRD_E_HIP);
+    const int rc = sepaihrd_eval_batch_device(ctx, ctx->d_theta, B, ctx->d_loglik, ctx->d_status, ctx->d_nacc, ctx->d_nrej,
+                                              ctx->d_parts, nullptr, ctx->own_stream);
+    if (rc != SEPAIHRD_OK) return rc;
+    ctx->pending_B = B;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_eval_batch_end(sepaihrd_ctx* ctx, double* loglik, int32_t* status, int32_t* n_accept, int32_t* n_reject,
+                            double* ll_parts) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    const int B = ctx->pending_B;
+    if (B <= 0) { ctx->last_error = "eval_batch_end: nothing pending"; return SEPAIHRD_E_INVALID_ARG; }
+    ctx->pending_B = 0;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    hipStream_t st = ctx->own_stream;
+    if (loglik) HIP_TRY(hipMemcpyAsync(loglik, ctx->d_loglik, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    if (status) HIP_TRY(hipMemcpyAsync(status, ctx->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    if (n_accept) HIP_TRY(hipMemcpyAsync(n_accept, ctx->d_nacc, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    if (n_reject) HIP_TRY(hipMemcpyAsync(n_reject, ctx->d_nrej, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    if (ll_parts) HIP_TRY(hipMemcpyAsync(ll_parts, ctx->d_parts, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(st), ctx, return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
 }
 

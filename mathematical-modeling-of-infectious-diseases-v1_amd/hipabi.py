@@ -57,7 +57,7 @@ class sepaihrd_kernel_info(C.Structure):
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
-    "sepaihrd_eval_batch_device", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
+    "sepaihrd_eval_batch_device", "sepaihrd_eval_batch_begin", "sepaihrd_eval_batch_end", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
     "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
     "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",

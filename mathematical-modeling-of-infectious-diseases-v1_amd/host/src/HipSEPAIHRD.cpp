@@ -461,11 +461,6 @@ double HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient(const Eigen:
     const double LOWEST = std::numeric_limits<double>::lowest();
     const int P = static_cast<int>(params.size());
     grad.resize(P);
-    const double f_center = HipSEPAIHRDObjectiveFunction::calculate(params);  // :22
-    if (!std::isfinite(f_center)) {  // :24-29
-        for (int i = 0; i < P; ++i) grad[i] = 0.0;
-        return f_center;
-    }
     std::vector<double> plus(static_cast<size_t>(P) * P), eps(static_cast<size_t>(P));
     for (int i = 0; i < P; ++i) {
         const double param_scale = std::max(std::abs(params[i]), epsilon_);
@@ -476,12 +471,25 @@ double HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient(const Eigen:
     std::vector<double> f_plus(static_cast<size_t>(P), LOWEST);
     std::vector<int32_t> status(static_cast<size_t>(P), 0);
     const bool rows_match = n_times_ == n_obs_rows_;
-    if (rows_match) {
-        if (first_time_ < 0.0)
-            throw InvalidParameterException("SEPAIHRDGradientObjectiveFunction",
-                                            "output grids that start before t = 0 with one observation row per output are not built");
-        const int rc = sepaihrd_eval_batch(grad_ctx_, plus.data(), P, f_plus.data(), status.data(), nullptr, nullptr, nullptr, nullptr);
-        if (rc != SEPAIHRD_OK) throw ModelException("SEPAIHRDGradientObjectiveFunction", sepaihrd_last_error(grad_ctx_));
+    if (rows_match && first_time_ < 0.0)
+        throw InvalidParameterException("SEPAIHRDGradientObjectiveFunction",
+                                        "output grids that start before t = 0 with one observation row per output are not built");
+    // The P perturbed simulations do not depend on the centre value: they are launched first, on their context's own
+    // stream, and run while calculate() evaluates the centre (the reference's order of the two is not observable).
+    if (rows_match && sepaihrd_eval_batch_begin(grad_ctx_, plus.data(), P) != SEPAIHRD_OK)
+        throw ModelException("SEPAIHRDGradientObjectiveFunction", sepaihrd_last_error(grad_ctx_));
+    double f_center;
+    try {
+        f_center = HipSEPAIHRDObjectiveFunction::calculate(params);  // :22
+    } catch (...) {
+        if (rows_match) (void)sepaihrd_eval_batch_end(grad_ctx_, nullptr, nullptr, nullptr, nullptr, nullptr);
+        throw;
+    }
+    if (rows_match && sepaihrd_eval_batch_end(grad_ctx_, f_plus.data(), status.data(), nullptr, nullptr, nullptr) != SEPAIHRD_OK)
+        throw ModelException("SEPAIHRDGradientObjectiveFunction", sepaihrd_last_error(grad_ctx_));
+    if (!std::isfinite(f_center)) {  // :24-29
+        for (int i = 0; i < P; ++i) grad[i] = 0.0;
+        return f_center;
     }
     for (int i = 0; i < P; ++i) {
         const size_t u = static_cast<size_t>(i);
