@@ -487,6 +487,10 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
         return SEPAIHRD_E_INVALID_ARG;
     }
     if (B == 0) return SEPAIHRD_OK;
+    if (!traj) {  // the common case: asynchronous copies on the context's stream and ONE wait
+        const int rc = sepaihrd_eval_batch_begin(ctx, theta, B);
+        return rc != SEPAIHRD_OK ? rc : sepaihrd_eval_batch_end(ctx, loglik, status, n_accept, n_reject, ll_parts);
+    }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const size_t traj_elems = traj ? (size_t)B * ctx->T * NUM_COMP * ctx->n : 0;
     if (ctx->pending_B > 0) { ctx->last_error = "eval_batch: a sepaihrd_eval_batch_begin is pending"; return SEPAIHRD_E_INVALID_ARG; }
