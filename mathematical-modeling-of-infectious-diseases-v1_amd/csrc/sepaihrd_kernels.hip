@@ -1173,7 +1173,7 @@ template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(batch))
-            return info_of(&sepaihrd_eval_quad_kernel<SOLVER>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
+            return info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name);
 }

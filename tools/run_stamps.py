@@ -15,10 +15,17 @@ theta = draws.jitter_draws(pb, 1, 4096)
 hip = mm.HipObjective(pb)
 hip.eval_batch(theta)
 r = hip.eval_batch(theta)
-parts = r["ll_parts"].reshape(-1, 16, 3)  # per wave: 16 chains
-head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
-tail, att, errA = parts[:, 1, 0], parts[:, 1, 1], parts[:, 1, 2]
-tailA = parts[:, 2, 0]
+quad = os.environ.get("SEPAIHRD_LANE_SPLIT", "") != "0"  # 4096 chains: the 16-lane form unless switched off
+if quad:
+    parts = r["ll_parts"].reshape(-1, 4, 3)   # per wave: 4 chains
+    head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
+    tail, att = parts[:, 1, 0], parts[:, 1, 1]
+    errA, tailA = err * 0, tail * 0             # sub-sections are stamped in the 4-lane kernel only
+else:
+    parts = r["ll_parts"].reshape(-1, 16, 3)  # per wave: 16 chains
+    head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
+    tail, att, errA = parts[:, 1, 0], parts[:, 1, 1], parts[:, 1, 2]
+    tailA = parts[:, 2, 0]
 tot = head + body + err + tail
 print("arith", arith, "waves", len(tot), "attempts/wave mean %.1f" % att.mean())
 for name, v in (("head(stage times, schedule)", head), ("RK body (6 RHS + stage sums + xerr)", body),
