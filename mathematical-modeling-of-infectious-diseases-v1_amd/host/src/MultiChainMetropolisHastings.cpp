@@ -365,7 +365,12 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     };
     std::vector<Light> chains(static_cast<size_t>(C));
     const size_t CP = static_cast<size_t>(C) * P;
-    std::vector<double> values(static_cast<size_t>(C)), z(CP), z_with_u(CP), scale(static_cast<size_t>(C)), prop(CP);
+    std::vector<double> values(static_cast<size_t>(C)), scale(static_cast<size_t>(C)), prop(CP);
+    // the normals of the proposal being evaluated (z) and of the next one (z_next): the roles swap every iteration,
+    // nothing is copied
+    std::vector<double> z_buffers[2] = {std::vector<double>(CP), std::vector<double>(CP)};
+    double* z = z_buffers[0].data();
+    double* z_next = z_buffers[1].data();
     std::vector<int32_t> status(static_cast<size_t>(C));
     std::vector<uint8_t> accept(static_cast<size_t>(C));
     auto sanitize_all = [&]() {
@@ -407,7 +412,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             check(sepaihrd_mh_adapt(mh, 10.0 / (t + 100.0), refresh ? 1 : 0, static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 1 : 0),
                   "mh_adapt");
         }
-        check(sepaihrd_mh_propose(mh, z.data(), scale.data(), nullptr, nullptr), "mh_propose");  // launch only
+        check(sepaihrd_mh_propose(mh, z, scale.data(), nullptr, nullptr), "mh_propose");  // launch only
         const auto p1 = now();
         const bool more = t + 1 < iterations_;
         if (more) {
@@ -421,7 +426,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 with_u = ch.gen[ch.cur];
                 std::uniform_real_distribution<double> u_dist(0.0, 1.0);
                 ch.u = u_dist(with_u);
-                draw_normals(with_u, &z_with_u[static_cast<size_t>(c) * P]);
+                draw_normals(with_u, &z_next[static_cast<size_t>(c) * P]);
             }
         }
         const auto p2 = now();
@@ -437,15 +442,14 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             bool acc = false;
             if (log_ratio >= 0.0) {
                 acc = true;
-                if (more) draw_normals(ch.gen[ch.cur], &z[static_cast<size_t>(c) * P]);  // the stream without the uniform
+                if (more) draw_normals(ch.gen[ch.cur], &z_next[static_cast<size_t>(c) * P]);  // the stream without the uniform
             } else {
                 double u = ch.u;
                 if (!more) {  // no speculation ran for the last iteration
                     std::uniform_real_distribution<double> u_dist(0.0, 1.0);
                     u = u_dist(ch.gen[ch.cur]);
                 } else {
-                    ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one
-                    std::copy_n(&z_with_u[static_cast<size_t>(c) * P], P, &z[static_cast<size_t>(c) * P]);
+                    ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one; its normals are in z_next
                 }
                 if (std::log(u) < log_ratio) acc = true;
             }
@@ -487,6 +491,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                     ch.best_x.assign(prop.begin() + static_cast<size_t>(c) * P, prop.begin() + static_cast<size_t>(c + 1) * P);
             }
         }
+        std::swap(z, z_next);
         const auto p4 = now();
         check(sepaihrd_mh_commit(mh, accept.data()), "mh_commit");
         if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
