@@ -191,6 +191,12 @@ int sepaihrd_eval_batch_end(sepaihrd_ctx *ctx, double *loglik, int32_t *status, 
  * for a larger batch; call sepaihrd_reserve first when the call must not allocate (stream capture).
  * Batches whose workspace would exceed 24 GiB (environment SEPAIHRD_WORKSPACE_MB at sepaihrd_create
  * overrides the budget) are evaluated in chunks of chains on the same stream. */
+/* A context is single-thread and holds ONE evaluation in flight: the launches of every entry point of a context
+ * share its workspace.  Calls on different streams are ordered by the library (the later launch waits for an event
+ * the earlier one left, hipStreamWaitEvent: nothing blocks on the host and nothing is added when the stream is the
+ * same); for evaluations that should overlap use one context per stream, as the grouped sampler and the
+ * finite-difference objective do.  Under stream capture the library records no event: a captured graph must not run
+ * concurrently with other launches of the same context. */
 int sepaihrd_eval_batch_device(sepaihrd_ctx *ctx, const double *d_theta, int B, double *d_loglik,
                                int32_t *d_status, int32_t *d_n_accept, int32_t *d_n_reject,
                                double *d_ll_parts, double *d_traj, void *stream);

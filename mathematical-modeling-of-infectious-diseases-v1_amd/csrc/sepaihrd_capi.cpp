@@ -54,6 +54,11 @@ struct sepaihrd_ctx {
     double* ws_rows = nullptr;
     int32_t* ws_status = nullptr;
     size_t ws_budget_bytes = (size_t)24 << 30;  // larger batches are evaluated in chunks of chains
+    // ONE evaluation in flight per context (they share the workspace above): the last launch sequence leaves an
+    // event, and a launch on a different stream waits for it first (free when the stream is the same)
+    hipEvent_t busy_event = nullptr;
+    hipStream_t busy_stream = nullptr;
+    bool busy_valid = false;
     // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // triples: before integrator, after integrator, after likelihood pass
@@ -131,6 +136,37 @@ int ensure_workspace(sepaihrd_ctx* c, size_t chains) {
     }
     c->ws_chains = chains;
     return SEPAIHRD_OK;
+}
+
+// Does a launch of B chains use the ctx-owned workspace?  Decided by the kernel translation unit (the launch code
+// takes the same branches); < 0: unsupported lanes-per-chain.
+int needs_workspace(const sepaihrd_ctx* c, int B, int force_split) {
+    return c->arith == SEPAIHRD_ARITH_FMA ? launch_needs_workspace_fma(c->dp, c->solver, B, force_split)
+                                          : launch_needs_workspace_strict(c->dp, c->solver, B, force_split);
+}
+
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
+// Order this launch sequence after the previous one of the same context when it runs on another stream.
+// Inside a stream capture nothing is recorded or waited for (the captured graph owns its ordering).
+int fence_before(sepaihrd_ctx* c, hipStream_t st) {
+    if (!c->busy_valid || c->busy_stream == st || stream_is_capturing(st)) return SEPAIHRD_OK;
+    if (hipStreamWaitEvent(st, c->busy_event, 0) != hipSuccess) {
+        c->last_error = "hipStreamWaitEvent on the context's previous evaluation failed";
+        return SEPAIHRD_E_HIP;
+    }
+    return SEPAIHRD_OK;
+}
+void fence_after(sepaihrd_ctx* c, hipStream_t st) {
+    if (stream_is_capturing(st)) return;
+    if (!c->busy_event && hipEventCreateWithFlags(&c->busy_event, hipEventDisableTiming) != hipSuccess) {
+        c->busy_event = nullptr;
+        return;
+    }
+    if (hipEventRecord(c->busy_event, st) == hipSuccess) { c->busy_stream = st; c->busy_valid = true; }
 }
 
 void free_staging(sepaihrd_ctx* c) {
@@ -378,6 +414,7 @@ void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     for (void* p : ctx->ens_buf)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->busy_event) (void)hipEventDestroy(ctx->busy_event);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
 }
@@ -414,13 +451,17 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
     if (B == 0) return SEPAIHRD_OK;
     // The workspace grows on the first call for a larger batch (an allocation: call sepaihrd_reserve
     // beforehand when the launch must be allocation-free, e.g. under stream capture).
-    const size_t cpw = (size_t)(WAVE / ctx->dp.lpc);
-    const size_t waves = ((size_t)B + cpw - 1) / cpw;
     // batches that fill the chip use the inline-likelihood kernel and need no workspace / chunking
-    const bool split = split_likelihood(ctx->solver, ctx->arith == SEPAIHRD_ARITH_FMA, waves);
+    const int needs = needs_workspace(ctx, B, 0);
+    if (needs < 0) { ctx->last_error = "unsupported lanes-per-chain"; return SEPAIHRD_E_UNSUPPORTED; }
+    const bool split = needs != 0;
     const size_t chunk = split ? chunk_chains(ctx, (size_t)B) : (size_t)B;
     if (split) {
         const int rc = ensure_workspace(ctx, chunk);
+        if (rc != SEPAIHRD_OK) return rc;
+    }
+    {
+        const int rc = fence_before(ctx, static_cast<hipStream_t>(stream));
         if (rc != SEPAIHRD_OK) return rc;
     }
     const size_t traj_per_chain = (size_t)ctx->T * NUM_COMP * ctx->n;
@@ -448,11 +489,14 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
         const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
                                                          : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
         if (rc != 0) {
-            ctx->last_error = rc == -4 ? "unsupported lanes-per-chain" : "kernel launch failed";
+            ctx->last_error = rc == -4 ? "unsupported lanes-per-chain"
+                              : rc == -5 ? "launch needs the likelihood workspace but none was sized for it"
+                                         : "kernel launch failed";
             return rc == -4 ? SEPAIHRD_E_UNSUPPORTED : SEPAIHRD_E_HIP;
         }
         if (e2) (void)hipEventRecord(e2, static_cast<hipStream_t>(stream));
     }
+    fence_after(ctx, static_cast<hipStream_t>(stream));
     return SEPAIHRD_OK;
 }
 
@@ -611,6 +655,10 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
             ctx->last_error = "ensemble_quantiles: probabilities must lie in [0, 1]";
             return SEPAIHRD_E_INVALID_ARG;
         }
+    if (ctx->pending_B > 0) {
+        ctx->last_error = "ensemble_quantiles: a sepaihrd_eval_batch_begin is pending on this context";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const DevProblem& dp = ctx->dp;
     const int Tp = dp.T - dp.runup_offset;
@@ -675,6 +723,8 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
             { cleanup(); return SEPAIHRD_E_HIP; });
     EvalOutputs out{d_ll, nullptr, nullptr, nullptr, nullptr, want_traj ? d_traj : nullptr,
                     ctx->ws_cum, ctx->ws_rows, ctx->ws_status, nullptr, 1};
+    rc = fence_before(ctx, nullptr);  // an evaluation of this context may still be running on another stream
+    if (rc != SEPAIHRD_OK) return rc;
     rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(dp, ctx->solver, d_theta, S, out, nullptr)
                                           : launch_eval_strict(dp, ctx->solver, d_theta, S, out, nullptr);
     if (rc != 0) {
@@ -811,11 +861,26 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         return nullptr;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->last_error = "hipSetDevice failed"; return nullptr; }
+    const size_t CP = (size_t)C * P, CPP = CP * P;
+    {
+        // the exact two-pass covariance refresh keeps every state of every chain (:168-199): say what that costs
+        // before allocating instead of failing somewhere inside
+        const double need = (double)CP * capacity * 8.0 + 2.0 * (double)CPP * 8.0 + 5.0 * (double)CP * 8.0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) {
+            char msg[256];
+            std::snprintf(msg, sizeof(msg),
+                          "mh_create: sampler state needs %.3f GB (history C*capacity*P = %d*%d*%d doubles, covariance + factor "
+                          "2*C*P*P) but %.3f GB of device memory are free; run fewer chains or iterations per sampler object",
+                          need / 1e9, C, capacity, P, (double)free_b / 1e9);
+            ctx->last_error = msg;
+            return nullptr;
+        }
+    }
     auto* mh = new sepaihrd_mh();
     mh->ctx = ctx;
     SamplerState& st = mh->st;
     st.C = C; st.P = P; st.capacity = capacity; st.scaling = scaling_factor; st.reg_eps = reg_eps;
-    const size_t CP = (size_t)C * P, CPP = CP * P;
     bool ok = true;
     auto dalloc = [&](void** p, size_t bytes) {
         if (!ok) return;

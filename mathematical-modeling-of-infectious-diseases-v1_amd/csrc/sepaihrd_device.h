@@ -84,6 +84,11 @@ int launch_eval_strict(const DevProblem& pb, int solver, const double* d_theta, 
                        const EvalOutputs& out, void* stream);
 int launch_eval_fma(const DevProblem& pb, int solver, const double* d_theta, int B,
                     const EvalOutputs& out, void* stream);
+// 1 when a launch of B chains parks its daily increments in the ctx-owned workspace (EvalOutputs::cum / rows /
+// wstatus must then be sized for it), 0 when the likelihood is evaluated inside the integrator, < 0 on error.
+// Decided in the kernel translation unit, next to the launch code that takes the same branches.
+int launch_needs_workspace_strict(const DevProblem& pb, int solver, int B, int force_split);
+int launch_needs_workspace_fma(const DevProblem& pb, int solver, int B, int force_split);
 // batch <= 0: the large-batch kernel
 int kernel_info_strict(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
 int kernel_info_fma(const DevProblem& pb, int solver, int batch, LaunchInfo* info);

@@ -1118,6 +1118,9 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
     const size_t lds = eval_lds_bytes(pb);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cum_chains = blocks * (WAVE / LPC);  // columns incl. the shadow groups of the last wave
+    if constexpr (!INLINE_LL) {
+        if (out.cum == nullptr || out.rows == nullptr || out.wstatus == nullptr) return -5;  // see needs_workspace_one()
+    }
     hipLaunchKernelGGL((sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, WPS, INLINE_LL>), dim3(blocks), dim3(WAVE), lds,
                        st, pb, d_theta, B, out, cum_chains);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
@@ -1135,6 +1138,19 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Does a launch of B chains park the daily increments in the ctx-owned workspace (cum / rows / wstatus)?  The ONE
+// place that decides it: launch_one below takes the same branches, and the C ABI sizes the workspace from this.
+template <int LPC, int SOLVER>
+int needs_workspace_one(const DevProblem&, int B, int force_split) {
+    constexpr int CPW = WAVE / LPC;
+    const int blocks = (B + CPW - 1) / CPW;
+    if (blocks <= 0) return 0;
+    if constexpr (LPC == 4) {
+        if (lane_split_wanted(B)) return 1;
+    }
+    return (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || force_split) ? 1 : 0;
+}
+
 template <int LPC, int SOLVER>
 int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOutputs& out, void* stream) {
     constexpr int CPW = WAVE / LPC;
@@ -1144,7 +1160,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
         if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
-    if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
+    if (needs_workspace_one<LPC, SOLVER>(pb, B, out.force_split))
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
         // two waves per SIMD only pay when there are two waves for every SIMD
@@ -1192,10 +1208,12 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
 
 #if SEPAIHRD_ARITH_FMA
 #define SEP_LAUNCH launch_eval_fma
+#define SEP_NEEDS_WS launch_needs_workspace_fma
 #define SEP_INFO kernel_info_fma
 #define SEP_NAME "sepaihrd_eval_kernel[fma]"
 #else
 #define SEP_LAUNCH launch_eval_strict
+#define SEP_NEEDS_WS launch_needs_workspace_strict
 #define SEP_INFO kernel_info_strict
 #define SEP_NAME "sepaihrd_eval_kernel[strict]"
 #endif
@@ -1203,6 +1221,9 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
 int SEP_LAUNCH(const DevProblem& pb, int solver, const double* d_theta, int B, const EvalOutputs& out,
                void* stream) {
     SEP_DISPATCH(launch_one, pb, d_theta, B, out, stream)
+}
+int SEP_NEEDS_WS(const DevProblem& pb, int solver, int B, int force_split) {
+    SEP_DISPATCH(needs_workspace_one, pb, B, force_split)
 }
 int SEP_INFO(const DevProblem& pb, int solver, int batch, LaunchInfo* info) {
     SEP_DISPATCH(info_one, pb, batch, info, SEP_NAME)

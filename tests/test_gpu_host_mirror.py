@@ -310,3 +310,28 @@ def test_device_resident_sampler_with_158_parameters(mm, oracle_py, shipped):
     dev = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
     for k in ("accept_trace", "accepted", "best_value", "best", "samples", "sample_values", "final_scale"):
         assert np.array_equal(dev[k], host[k]), k
+
+
+@pytest.mark.parametrize("problem", ["headline", "shipped"])
+def test_device_sampler_accept_traces_in_production_arithmetic(mm, oracle_py, synth400, shipped, problem):
+    """The arithmetic bench.py's headline number is measured in (fma: contraction, folded constants, hardware
+    log2 / exp2 in the step-size factor) against the bit-exact contract of the north star: device-resident
+    Adaptive-Metropolis, fixed seed, 6 chains x 400 iterations with covariance refreshes -- accept/reject
+    sequences and accepted counts EQUAL the oracle's strict-arithmetic MetropolisHastingsSampler restatement
+    (MetropolisHastingsSampler.cpp:283-351), hence the stored samples are the same bits; the log-likelihoods
+    agree to 1e-7 relative.  (A likelihood that differs in the 9th digit can flip an accept test whose uniform
+    falls inside that gap: for these seeds none does.)"""
+    pb = (synth400 if problem == "headline" else shipped).with_(arith=mm.ARITH_FMA, constraint_mode=1, solver=0)
+    C, iters, burn, ap = 6, 400, 100, 50
+    x0 = oracle_py.Oracle(pb).jitter_draws(pb.base_theta, 41, C, mode=1)
+    kw = dict(iterations=iters, burn_in=burn, adaptation_period=ap, thinning=5)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, seed=31, device_state=True, **kw)
+    assert 0 < dev["accept_trace"].sum() < dev["accept_trace"].size
+    orc = oracle_py.Oracle(pb.with_(arith=mm.ARITH_STRICT))
+    for c in range(C):
+        ref = orc.metropolis_hastings(x0[c], 31 + c, iters, burn, adaptation_period=ap, thinning=5)
+        assert np.array_equal(dev["accept_trace"][c], ref["accept_trace"]), c
+        assert dev["accepted"][c] == ref["accepted"]
+        assert np.array_equal(dev["samples"][c], ref["samples"])
+        np.testing.assert_allclose(dev["sample_values"][c], ref["sample_values"], rtol=1e-7)
+        np.testing.assert_allclose(dev["final_scale"][c], ref["final_scale"], rtol=1e-14)

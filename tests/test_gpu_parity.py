@@ -372,3 +372,103 @@ def test_small_batch_kernel_fuzz(arith, solver, seed):
     r = subprocess.run([sys.executable, tool, "--problem", "shipped_problem.json", "--arith", arith, "--solver", str(solver),
                         "--fuzz", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all arrays identical=True" in r.stdout, r.stdout + r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE-size parity (round 2): the whole headline batch and the configs[4] workload against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("solver", [0, 1])
+def test_headline_batch_matches_oracle_chain_by_chain(mm, oracle_py, solver):
+    """BASELINE configs[1] exactly as bench.py runs it (4096 jittered chains, 400 days, T = 401; solver 1 = the
+    Cash-Karp stepper of configs[2] on the same batch), strict arithmetic: EVERY chain has the oracle's accepted /
+    rejected step counts and status, every trajectory state agrees to 1e-9 relative (north-star bar 1e-6), every
+    log-likelihood to 1e-8 relative (the daily increments of the cumulative compartments amplify the 1e-13 state
+    differences; measured 1.3e-9)."""
+    from mmid_amd import draws as dr
+    pb = mm.workloads.build("c1", os.path.join(os.path.dirname(__file__), "golden")).with_(arith=mm.ARITH_STRICT, solver=solver)
+    theta = dr.jitter_draws(pb, 1, 4096)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"]) and np.all(ref["status"] == 0)
+    assert np.array_equal(got["n_accept"], ref["n_accept"])
+    assert np.array_equal(got["n_reject"], ref["n_reject"])
+    worst = 0.0
+    for lo in range(0, 4096, 512):  # in slices: the difference array of the whole batch is another 0.6 GB
+        worst = max(worst, rel_state_err(got["traj"][lo:lo + 512], ref["traj"][lo:lo + 512], pb).max())
+    assert worst < 1e-9, worst
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-8)
+
+
+@pytest.fixture(scope="module")
+def c5_problem(mm):
+    """BASELINE configs[4]: 16 age groups, t = -20 .. 980 (T = 1001), synthetic Poisson observations drawn from the
+    base-theta trajectory (workloads.build("c5"), what bench.py --workload c5 runs)."""
+    return mm.workloads.build("c5", os.path.join(os.path.dirname(__file__), "golden"),
+                              hip_factory=lambda q: mm.HipObjective(q))
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_config5_workload_strict_matches_oracle(mm, oracle_py, c5_problem, solver):
+    """configs[4] at its own size in time and age (T = 1001, n = 16, 158 parameters), 70 chains (a ragged last wave
+    of the 4-chains-per-wave layout), strict arithmetic: identical step counts, states 1e-9, likelihood 1e-9."""
+    from mmid_amd import draws as dr
+    pb = c5_problem.with_(arith=mm.ARITH_STRICT, solver=solver)
+    assert pb.n == 16 and pb.n_times == 1001
+    theta = dr.jitter_draws(pb, 1, 70)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"]) and np.all(ref["status"] == 0)
+    assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    assert np.all(got["n_accept"] >= 1000)
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-9)
+
+
+def test_config5_workload_production_arithmetic(mm, oracle_py, c5_problem):
+    """The same workload in the fma arithmetic bench.py --workload c5 times: states within the north-star 1e-6
+    (measured ~1e-10), likelihood 1e-7, step counts identical for at least 90 % of the chains."""
+    from mmid_amd import draws as dr
+    pb = c5_problem.with_(arith=mm.ARITH_FMA, solver=0)
+    theta = dr.jitter_draws(pb, 1, 70)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    assert np.array_equal(got["status"], ref["status"])
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < REL_STATE_BAR
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-7)
+    same = (got["n_accept"] == ref["n_accept"]) & (got["n_reject"] == ref["n_reject"])
+    assert same.mean() >= 0.9
+
+
+def test_forced_small_batch_form_sizes_its_own_workspace():
+    """SEPAIHRD_LANE_SPLIT=1 sends a strict batch of more than 16 384 chains to the 16-lane integrator, which parks
+    its increments in the workspace; the C ABI must size it from the SAME decision the launch code takes (no prior
+    sepaihrd_reserve), and the results are the default path's bits.  Own process: the switch is read once."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import mmid_amd_loader; mm = mmid_amd_loader.load()\n"
+        "pb = mm.SEPAIHRDProblem.load(os.path.join(%r, 'tests', 'golden', 'synth_400d_n4.json')).with_(arith=mm.ARITH_STRICT)\n"
+        "pb.times = pb.times[:60]\n"
+        "pb = pb.with_(obs_H=pb.obs_H[:40], obs_ICU=pb.obs_ICU[:40], obs_D=pb.obs_D[:40])\n"
+        "from mmid_amd import draws\n"
+        "theta = np.tile(draws.jitter_draws(pb, 1, 1024), (17, 1))[:16384 + 777]\n"
+        "out = mm.HipObjective(pb).eval_batch(theta)\n"
+        "assert np.all(out['status'] == 0)\n"
+        "np.save(sys.argv[1], out['loglik'])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for mode in ("1", "unset"):
+            env = dict(os.environ)
+            env.pop("SEPAIHRD_LANE_SPLIT", None)
+            if mode == "1":
+                env["SEPAIHRD_LANE_SPLIT"] = "1"
+            path = os.path.join(tmp, mode + ".npy")
+            r = subprocess.run([sys.executable, "-c", code % (root, root), path], capture_output=True, text=True,
+                               timeout=600, env=env)
+            assert r.returncode == 0, r.stdout + r.stderr
+            res[mode] = np.load(path)
+        assert np.array_equal(res["1"], res["unset"])
