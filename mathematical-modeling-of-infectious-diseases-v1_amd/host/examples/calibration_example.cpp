@@ -1,8 +1,9 @@
 // host/examples/calibration_example.cpp
 //
-// What a caller of the reference writes, against the device path: the objects that
-// SEPAIHRDModelCalibration::setupCalibrator builds (src/model/SEPAIHRDModelCalibration.cpp:94-118) and the
-// run of runHillClimbingMCMC (:150-178), followed by the post-calibration ensemble
+// What a caller of the reference writes, against the device path: the model and its NPI strategy (main.cpp:222-242),
+// the objects SEPAIHRDModelCalibration::setupCalibrator builds from them
+// (src/model/SEPAIHRDModelCalibration.cpp:84-118) WITH THE REFERENCE'S OWN ARGUMENT LISTS -- only the two class names
+// differ -- and the run of runHillClimbingMCMC (:150-178), followed by the post-calibration ensemble
 // (src/model/main.cpp:505-560).  Self-contained: a 4-age-group problem with synthetic observations.
 //
 //   make -C host examples && host/examples/calibration_example      (needs an MI355X)
@@ -37,15 +38,18 @@ int main() {
     mp.d_H = vec4(0.01, 0.02, 0.05, 0.1); mp.d_ICU = vec4(0.2, 0.3, 0.4, 0.5); mp.d_community = vec4(0, 0, 0, 0);
     mp.beta = 0.05; mp.theta = 0.5; mp.sigma = 1.0 / 3; mp.gamma_p = 0.5; mp.gamma_A = 0.2; mp.gamma_I = 0.2;
     mp.gamma_H = 0.1; mp.gamma_ICU = 1.0 / 14;
-    mp.kappa_end_times = {13, 40, 70, 305};
-    mp.kappa_values = {1.0, 0.5, 0.7, 0.9};
     mp.runup_days = 0.0; mp.seed_exposed = 0.0;  // multiplier branch of the initial state
+    // kappa(t): baseline 1.0 until day 13, then three calibratable periods (named kappa_2 .. kappa_4 by default)
+    auto npi = std::make_shared<PiecewiseConstantNpiStrategy>(std::vector<double>{40, 70, 305}, std::vector<double>{0.5, 0.7, 0.9},
+                                                               std::map<std::string, std::pair<double, double>>{}, 1.0, 13.0);
+    auto model = std::make_shared<AgeSEPAIHRDModel>(mp, npi);
 
     const std::vector<std::string> names = {"beta", "theta", "kappa_2", "kappa_3", "kappa_4"};
     std::map<std::string, double> sigmas = {{"beta", 0.005}, {"theta", 0.02}, {"kappa_2", 0.05}, {"kappa_3", 0.05}, {"kappa_4", 0.05}};
     std::map<std::string, std::pair<double, double>> bounds = {
         {"beta", {0.01, 1.0}}, {"theta", {0.1, 1.0}}, {"kappa_2", {0.1, 1.5}}, {"kappa_3", {0.1, 1.5}}, {"kappa_4", {0.1, 1.5}}};
-    HipSEPAIHRDParameterManager pm(mp, names, sigmas, bounds);
+    // reference: std::make_unique<SEPAIHRDParameterManager>(model_, params_to_calibrate_, proposal_sigmas_, param_bounds_)
+    HipSEPAIHRDParameterManager pm(model, names, sigmas, bounds);
 
     std::vector<double> times(days);
     for (int t = 0; t < days; ++t) times[static_cast<size_t>(t)] = t;
@@ -76,7 +80,9 @@ int main() {
     auto solver = std::make_shared<Dopri5SolverStrategy>();
 
     try {
-        HipSEPAIHRDObjectiveFunction objective(pm, cache, data, times, x0, solver);
+        // reference: std::make_unique<SEPAIHRDObjectiveFunction>(model_, *parameterManager, *cache_, observed_data_,
+        //                                                         time_points_, initial_state_cached_, solver_strategy_)
+        HipSEPAIHRDObjectiveFunction objective(model, pm, cache, data, times, x0, solver);
         HipModelCalibrator calibrator(pm, objective);
         std::printf("initial log-likelihood   %.6f\n", calibrator.getInitialObjectiveValue());
 
@@ -88,7 +94,7 @@ int main() {
         const Eigen::VectorXd& best = calibrator.getBestParameterVector();
         for (size_t i = 0; i < names.size(); ++i) std::printf("  %-8s %.6f\n", names[i].c_str(), best[static_cast<Eigen::Index>(i)]);
 
-        HipSEPAIHRDGradientObjectiveFunction gradient(pm, cache, data, times, x0, solver);
+        HipSEPAIHRDGradientObjectiveFunction gradient(model, pm, cache, data, times, x0, solver);
         Eigen::VectorXd g;
         const double f = gradient.evaluate_with_gradient(best, g);
         std::printf("gradient at the optimum  f = %.6f  d/dbeta = %.4g  d/dtheta = %.4g\n", f, g[0], g[1]);

@@ -19,26 +19,14 @@
 #include <random>
 #include <unordered_map>
 
+#include "AgeSEPAIHRDModel.hpp"
 #include "Interfaces.hpp"
 
 struct sepaihrd_ctx;
 
 namespace epidemic {
 
-// include/model/parameters/SEPAIHRDParameters.hpp:20-124 (fields used on this path)
-struct SEPAIHRDParameters {
-    Eigen::VectorXd N;
-    Eigen::MatrixXd M_baseline;
-    double beta = 0.0;
-    std::vector<double> beta_end_times, beta_values;
-    Eigen::VectorXd a, h_infec;
-    double theta = 0, sigma = 0, gamma_p = 0, gamma_A = 0, gamma_I = 0, gamma_H = 0, gamma_ICU = 0;
-    Eigen::VectorXd p, h, icu, d_H, d_ICU, d_community;
-    std::vector<double> kappa_end_times, kappa_values;  // baseline period first
-    double E0_multiplier = 1, P0_multiplier = 1, A0_multiplier = 1, I0_multiplier = 1, H0_multiplier = 1,
-           ICU0_multiplier = 1, R0_multiplier = 1, D0_multiplier = 1;
-    double runup_days = 30.0, seed_exposed = 10.0;
-};
+// SEPAIHRDParameters, PiecewiseConstantNpiStrategy, AgeSEPAIHRDModel: AgeSEPAIHRDModel.hpp
 
 // include/model/parameters/SEPAIHRDParameterManager.hpp:22-25
 enum class ConstraintMode { OPTIMIZATION_CLAMP = 0, MCMC_REFLECT = 1 };
@@ -83,6 +71,12 @@ private:
 
 class HipSEPAIHRDParameterManager : public IParameterManager {
 public:
+    // The reference's constructor (include/model/parameters/SEPAIHRDParameterManager.hpp:40-45,
+    // SEPAIHRDModelCalibration.cpp:84-87): parameters and calibratable kappa names are read from the model
+    // (getModelParameters(), the PiecewiseConstantNpiStrategy's names); updateModelParameters() writes back into it.
+    HipSEPAIHRDParameterManager(std::shared_ptr<AgeSEPAIHRDModel> model, const std::vector<std::string>& params_to_calibrate,
+                                const std::map<std::string, double>& proposal_sigmas,
+                                const std::map<std::string, std::pair<double, double>>& param_bounds);
     // npi_param_names: names of kappa_values[1..] (PiecewiseConstantNpiStrategy's calibratable names;
     // empty -> "kappa_2", "kappa_3", ...)
     HipSEPAIHRDParameterManager(const SEPAIHRDParameters& model_params,
@@ -108,6 +102,7 @@ public:
     bool hasBounds(int idx) const { return has_bounds_[static_cast<size_t>(idx)] != 0; }
 private:
     double* slot(int field, int index);
+    std::shared_ptr<AgeSEPAIHRDModel> model_;  // null for the struct-taking constructor
     SEPAIHRDParameters params_;
     std::vector<std::string> names_, npi_names_;
     std::vector<double> sigma_, lower_, upper_;
@@ -118,6 +113,20 @@ private:
 
 class HipSEPAIHRDObjectiveFunction : public virtual IObjectiveFunction, public IBatchObjectiveFunction {
 public:
+    // SEPAIHRDObjectiveFunction's constructor, argument for argument
+    // (include/model/objectives/SEPAIHRDObjectiveFunction.hpp:49-58; built at SEPAIHRDModelCalibration.cpp:94-118).
+    // parameterManager may be ANY IParameterManager whose names follow the reference's naming -- a
+    // HipSEPAIHRDParameterManager is used as it is; for any other (the reference's own SEPAIHRDParameterManager) the
+    // name -> field map is resolved here from getParameterNames(), the bounds and sigmas from its getters and the base
+    // values from model->getModelParameters(), and its CURRENT constraint mode is read before every evaluation by
+    // probing applyConstraints() with a vector beyond the bounds (the interface has no mode getter).
+    // Device and arithmetic: environment SEPAIHRD_DEVICE (default: current device), SEPAIHRD_ARITH=strict|fma
+    // (default strict: the CPU build's operation sequence).
+    HipSEPAIHRDObjectiveFunction(std::shared_ptr<AgeSEPAIHRDModel> model, IParameterManager& parameterManager,
+                                 ISimulationCache& cache, const CalibrationData& calibration_data,
+                                 const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+                                 std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error = 1.0e-6,
+                                 double rel_error = 1.0e-6);
     // Same argument order and meaning as SEPAIHRDObjectiveFunction's constructor; the model object is
     // the parameter manager's SEPAIHRDParameters (the device needs no host model instance).
     HipSEPAIHRDObjectiveFunction(HipSEPAIHRDParameterManager& parameterManager, ISimulationCache& cache,
@@ -147,6 +156,13 @@ protected:
                                        double rel_error, int device, bool fma_arithmetic,
                                        const double* multipliers_override);
     void syncConstraintMode() const;
+    // resolves the manager argument of the model-taking constructors: `owned` is filled when it is not a Hip manager
+    static HipSEPAIHRDParameterManager& resolveManager(const std::shared_ptr<AgeSEPAIHRDModel>& model, IParameterManager& given,
+                                                       std::unique_ptr<HipSEPAIHRDParameterManager>& owned);
+    static int environmentDevice();
+    static bool environmentFma();
+    std::unique_ptr<HipSEPAIHRDParameterManager> owned_pm_;  // declared before pm_: it may be what pm_ refers to
+    IParameterManager* foreign_pm_ = nullptr;                // the caller's manager when it is not a Hip one
     HipSEPAIHRDParameterManager& pm_;
     ISimulationCache& cache_;
     sepaihrd_ctx* ctx_ = nullptr;
@@ -163,6 +179,12 @@ protected:
 // observations' makes every entry (lowest() - f) / eps, as in the reference).
 class HipSEPAIHRDGradientObjectiveFunction : public HipSEPAIHRDObjectiveFunction, public IGradientObjectiveFunction {
 public:
+    // SEPAIHRDGradientObjectiveFunction's constructor (SEPAIHRDModelCalibration.cpp:96-104), as above
+    HipSEPAIHRDGradientObjectiveFunction(std::shared_ptr<AgeSEPAIHRDModel> model, IParameterManager& parameterManager,
+                                         ISimulationCache& cache, const CalibrationData& calibration_data,
+                                         const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+                                         std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error = 1.0e-6,
+                                         double rel_error = 1.0e-6);
     HipSEPAIHRDGradientObjectiveFunction(HipSEPAIHRDParameterManager& parameterManager, ISimulationCache& cache,
                                          const CalibrationData& calibration_data, const std::vector<double>& time_points,
                                          const Eigen::VectorXd& initial_state,
@@ -174,6 +196,9 @@ public:
     double calculate(const Eigen::VectorXd& parameters) const override { return HipSEPAIHRDObjectiveFunction::calculate(parameters); }
     const std::vector<std::string>& getParameterNames() const override { return HipSEPAIHRDObjectiveFunction::getParameterNames(); }
 private:
+    void buildGradientContext(const CalibrationData& data, const std::vector<double>& time_points,
+                              const std::shared_ptr<IOdeSolverStrategy>& solver_strategy, double abs_error, double rel_error,
+                              int device, bool fma_arithmetic);
     bool initialStateValid(const double* plus) const;
     sepaihrd_ctx* grad_ctx_ = nullptr;
     Eigen::VectorXd initial_state_;

@@ -5,6 +5,8 @@
 //   IOptimizationAlgorithm  include/sir_age_structured/interfaces/IOptimizationAlgorithm.hpp:18-54
 //   ISimulationCache        include/sir_age_structured/interfaces/ISimulationCache.hpp:13-62
 //   IOdeSolverStrategy      include/sir_age_structured/interfaces/IOdeSolverStrategy.hpp:18-43
+//   IEpidemicModel          include/sir_age_structured/interfaces/IEpidemicModel.hpp:24-92
+//   INpiStrategy            include/model/interfaces/INpiStrategy.hpp:14-65
 //   exceptions              include/exceptions/Exceptions.hpp:18-174
 // Inside the reference tree these declarations are replaced by the reference's own headers (see
 // INTEGRATION.md); nothing here adds or changes a virtual.
@@ -12,6 +14,7 @@
 #include <functional>
 #include <limits>
 #include <map>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -28,6 +31,34 @@ public:
 };
 class InvalidParameterException : public ModelException { using ModelException::ModelException; };
 class SimulationException : public ModelException { using ModelException::ModelException; };
+
+// The model-side surface (six pure virtuals).  On the device path computeDerivatives is never called -- the RHS
+// runs inside the HIP kernel -- but the objective's constructor takes a model through this interface, like the
+// reference's, and reads its parameters (AgeSEPAIHRDModel.hpp).
+class IEpidemicModel {
+public:
+    virtual ~IEpidemicModel() = default;
+    virtual void computeDerivatives(const std::vector<double>& state, std::vector<double>& derivatives, double time) = 0;
+    virtual void applyIntervention(const std::string& name, double time, const Eigen::VectorXd& params) = 0;
+    virtual void reset() = 0;
+    virtual int getStateSize() const = 0;
+    virtual std::vector<std::string> getStateNames() const = 0;
+    virtual int getNumAgeClasses() const = 0;
+};
+
+class INpiStrategy {
+public:
+    virtual ~INpiStrategy() = default;
+    virtual double getReductionFactor(double time) const = 0;
+    virtual const std::vector<double>& getEndTimes() const = 0;
+    virtual std::vector<double> getValues() const = 0;
+    virtual double getBaselineKappa() const = 0;
+    virtual double getBaselinePeriodEndTime() const = 0;
+    virtual void setValues(const std::vector<double>& new_values) = 0;
+    virtual std::shared_ptr<INpiStrategy> clone() const = 0;
+    virtual double getLowerBoundForParamIndex(int idx) const = 0;
+    virtual double getUpperBoundForParamIndex(int idx) const = 0;
+};
 
 class IObjectiveFunction {
 public:

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -170,6 +171,37 @@ HipSEPAIHRDParameterManager::HipSEPAIHRDParameterManager(
     }
 }
 
+namespace {
+// names of kappa_values[1..] as the model's strategy spells them (SEPAIHRDParameterManager.cpp:63-88)
+std::vector<std::string> npiNamesOf(const std::shared_ptr<AgeSEPAIHRDModel>& model) {
+    if (!model) throw InvalidParameterException("SEPAIHRDParameterManager", "Model pointer cannot be null.");
+    auto base = model->getNpiStrategy();
+    auto piecewise = std::dynamic_pointer_cast<PiecewiseConstantNpiStrategy>(base);
+    if (!piecewise)
+        throw ModelException("SEPAIHRDParameterManager", "NPI strategy is not a PiecewiseConstantNpiStrategy, cannot resolve kappa names.");
+    if (!piecewise->isBaselineFixed())
+        throw InvalidParameterException("SEPAIHRDParameterManager",
+                                        "a calibratable baseline kappa (kappa_baseline) is not built on the device path: kappa_1 is fixed");
+    std::vector<std::string> names;
+    for (size_t k = 0; k < piecewise->getNumCalibratableNpiParams(); ++k) names.push_back(piecewise->getNpiParamName(static_cast<int>(k)));
+    return names;
+}
+const SEPAIHRDParameters& checkedParameters(const std::shared_ptr<AgeSEPAIHRDModel>& model, SEPAIHRDParameters& storage) {
+    if (!model) throw InvalidParameterException("SEPAIHRDParameterManager", "Model pointer cannot be null.");
+    storage = model->getModelParameters();
+    return storage;
+}
+}  // namespace
+
+HipSEPAIHRDParameterManager::HipSEPAIHRDParameterManager(std::shared_ptr<AgeSEPAIHRDModel> model,
+                                                         const std::vector<std::string>& params_to_calibrate,
+                                                         const std::map<std::string, double>& proposal_sigmas,
+                                                         const std::map<std::string, std::pair<double, double>>& param_bounds)
+    : HipSEPAIHRDParameterManager([&]() -> SEPAIHRDParameters { SEPAIHRDParameters p; return checkedParameters(model, p); }(),
+                                  params_to_calibrate, proposal_sigmas, param_bounds, npiNamesOf(model)) {
+    model_ = std::move(model);
+}
+
 double* HipSEPAIHRDParameterManager::slot(int field, int index) {
     SEPAIHRDParameters& p = params_;
     switch (field) {
@@ -229,6 +261,11 @@ void HipSEPAIHRDParameterManager::updateModelParameters(const Eigen::VectorXd& p
         for (size_t k = 1; k < params_.kappa_values.size(); ++k)
             if (params_.kappa_values[k] < 0.0)
                 throw InvalidParameterException("PiecewiseConstantNpiStrategy::setCalibratableValues", "All NPI kappa values must be non-negative.");
+    if (model_) {  // the reference's manager writes into the model it was given (:269-286)
+        model_->setModelParameters(params_);
+        if (kappa_touched)
+            model_->getNpiStrategy()->setValues(std::vector<double>(params_.kappa_values.begin() + 1, params_.kappa_values.end()));
+    }
 }
 
 double HipSEPAIHRDParameterManager::getSigmaForParamIndex(int index) const {
@@ -361,12 +398,76 @@ sepaihrd_ctx* HipSEPAIHRDObjectiveFunction::createContext(
     return ctx;
 }
 
+int HipSEPAIHRDObjectiveFunction::environmentDevice() {
+    const char* e = std::getenv("SEPAIHRD_DEVICE");
+    return e ? std::atoi(e) : -1;
+}
+bool HipSEPAIHRDObjectiveFunction::environmentFma() {
+    const char* e = std::getenv("SEPAIHRD_ARITH");
+    return e && std::string(e) == "fma";
+}
+
+HipSEPAIHRDParameterManager& HipSEPAIHRDObjectiveFunction::resolveManager(
+    const std::shared_ptr<AgeSEPAIHRDModel>& model, IParameterManager& given, std::unique_ptr<HipSEPAIHRDParameterManager>& owned) {
+    const char* W = "SEPAIHRDObjectiveFunction";
+    if (!model) throw InvalidParameterException(W, "Model pointer cannot be null.");
+    if (auto* hip = dynamic_cast<HipSEPAIHRDParameterManager*>(&given)) {
+        if (static_cast<int>(hip->modelParameters().N.size()) != model->getNumAgeClasses())
+            throw InvalidParameterException(W, "parameter manager and model disagree on the number of age classes");
+        return *hip;
+    }
+    // any other manager: same names, sigmas and bounds, resolved once against the model's parameters
+    const std::vector<std::string>& names = given.getParameterNames();
+    std::map<std::string, double> sigmas;
+    std::map<std::string, std::pair<double, double>> bounds;
+    for (size_t i = 0; i < names.size(); ++i) {
+        const int k = static_cast<int>(i);
+        sigmas[names[i]] = given.getSigmaForParamIndex(k);
+        bounds[names[i]] = {given.getLowerBoundForParamIndex(k), given.getUpperBoundForParamIndex(k)};
+    }
+    owned = std::make_unique<HipSEPAIHRDParameterManager>(model->getModelParameters(), names, sigmas, bounds, npiNamesOf(model));
+    return *owned;
+}
+
+HipSEPAIHRDObjectiveFunction::HipSEPAIHRDObjectiveFunction(
+    std::shared_ptr<AgeSEPAIHRDModel> model, IParameterManager& parameterManager, ISimulationCache& cache,
+    const CalibrationData& data, const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+    std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error, double rel_error)
+    : pm_(resolveManager(model, parameterManager, owned_pm_)), cache_(cache) {
+    if (owned_pm_) foreign_pm_ = &parameterManager;
+    syncConstraintMode();  // a foreign manager's mode, before the context is built with it
+    ctx_ = createContext(pm_, data, time_points, initial_state, solver_strategy, abs_error, rel_error, environmentDevice(),
+                         environmentFma(), nullptr);
+    device_mode_ = pm_.getConstraintMode() == ConstraintMode::MCMC_REFLECT ? SEPAIHRD_CONSTRAINT_REFLECT : SEPAIHRD_CONSTRAINT_CLAMP;
+}
+
 HipSEPAIHRDObjectiveFunction::~HipSEPAIHRDObjectiveFunction() { sepaihrd_destroy(ctx_); }
 
 const std::vector<std::string>& HipSEPAIHRDObjectiveFunction::getParameterNames() const { return pm_.getParameterNames(); }
 
 void HipSEPAIHRDObjectiveFunction::syncConstraintMode() const {
     // the reference consults the SHARED parameter manager's mode_ on every evaluation
+    if (foreign_pm_) {
+        // IParameterManager has no mode getter: a value a quarter width above the upper bound comes back AS the bound
+        // under OPTIMIZATION_CLAMP and mirrored below it under MCMC_REFLECT (SEPAIHRDParameterManager.cpp:302-347)
+        const size_t P = pm_.getParameterCount();
+        Eigen::VectorXd probe = pm_.getCurrentParameters();
+        int k = -1;
+        for (size_t i = 0; i < P && k < 0; ++i) {
+            const double lo = pm_.getLowerBoundForParamIndex(static_cast<int>(i)), hi = pm_.getUpperBoundForParamIndex(static_cast<int>(i));
+            if (hi > lo && std::isfinite(hi - lo)) k = static_cast<int>(i);
+        }
+        if (k >= 0) {
+            const double lo = pm_.getLowerBoundForParamIndex(k), hi = pm_.getUpperBoundForParamIndex(k);
+            for (size_t i = 0; i < P; ++i) {  // the other entries sit inside their bounds
+                const double l = pm_.getLowerBoundForParamIndex(static_cast<int>(i)), h = pm_.getUpperBoundForParamIndex(static_cast<int>(i));
+                probe[static_cast<Eigen::Index>(i)] = std::min(std::max(probe[static_cast<Eigen::Index>(i)], std::min(l, h)), std::max(l, h));
+            }
+            probe[k] = hi + 0.25 * (hi - lo);
+            const double back = foreign_pm_->applyConstraints(probe)[k];
+            pm_.setConstraintMode(back < hi ? ConstraintMode::MCMC_REFLECT : ConstraintMode::OPTIMIZATION_CLAMP);
+        }
+    }
     const int want = pm_.getConstraintMode() == ConstraintMode::MCMC_REFLECT ? SEPAIHRD_CONSTRAINT_REFLECT : SEPAIHRD_CONSTRAINT_CLAMP;
     if (want != device_mode_) { sepaihrd_set_constraint_mode(ctx_, want); device_mode_ = want; }
 }
@@ -420,6 +521,24 @@ HipSEPAIHRDGradientObjectiveFunction::HipSEPAIHRDGradientObjectiveFunction(
                                    rel_error, device, fma_arithmetic),
       initial_state_(initial_state), n_times_(time_points.size()),
       n_obs_rows_(static_cast<size_t>(data.getNewDeaths().rows())), first_time_(time_points.empty() ? 0.0 : time_points.front()) {
+    buildGradientContext(data, time_points, solver_strategy, abs_error, rel_error, device, fma_arithmetic);
+}
+
+HipSEPAIHRDGradientObjectiveFunction::HipSEPAIHRDGradientObjectiveFunction(
+    std::shared_ptr<AgeSEPAIHRDModel> model, IParameterManager& parameterManager, ISimulationCache& cache,
+    const CalibrationData& data, const std::vector<double>& time_points, const Eigen::VectorXd& initial_state,
+    std::shared_ptr<IOdeSolverStrategy> solver_strategy, double abs_error, double rel_error)
+    : HipSEPAIHRDObjectiveFunction(std::move(model), parameterManager, cache, data, time_points, initial_state, solver_strategy,
+                                   abs_error, rel_error),
+      initial_state_(initial_state), n_times_(time_points.size()),
+      n_obs_rows_(static_cast<size_t>(data.getNewDeaths().rows())), first_time_(time_points.empty() ? 0.0 : time_points.front()) {
+    buildGradientContext(data, time_points, solver_strategy, abs_error, rel_error, environmentDevice(), environmentFma());
+}
+
+void HipSEPAIHRDGradientObjectiveFunction::buildGradientContext(const CalibrationData& data, const std::vector<double>& time_points,
+                                                                const std::shared_ptr<IOdeSolverStrategy>& solver_strategy,
+                                                                double abs_error, double rel_error, int device, bool fma_arithmetic) {
+    const Eigen::VectorXd& initial_state = initial_state_;
     // perturbed runs: multipliers default to 1.0 unless calibrated (:59-72), always the multiplier rule
     const double ones[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     const ConstraintMode keep = pm_.getConstraintMode();

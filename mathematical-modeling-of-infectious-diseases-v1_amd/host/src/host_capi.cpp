@@ -1,5 +1,6 @@
 // host_capi.cpp -- flat C entry points over the C++ host mirror, for the Python test-suite only.
 // The layout of `sepaihrd_problem` is reused as the carrier of the model / data arrays.
+#include <cstdio>
 #include <cstring>
 #include <sstream>
 
@@ -524,3 +525,146 @@ int host_mh_run_groups(void** handles, int G, int C, const double* initial, uint
 }
 
 }  // extern "C"
+
+// The reference-shaped constructors (SEPAIHRDModelCalibration.cpp:84-118): model -> parameter manager -> objective,
+// argument for argument, (a) with a HipSEPAIHRDParameterManager built from the model and (b) with an IParameterManager
+// that is NOT one (forwards to a private manager: stands for the reference's own SEPAIHRDParameterManager), whose
+// constraint mode is flipped behind the objective's back between evaluations.
+// values: [2 managers][2 modes: clamp, reflect][B]; model_back: the calibrated entries read back from the MODEL after
+// updateModelParameters(thetas[0]) in clamp mode, [P].
+namespace {
+class ForwardingManager : public IParameterManager {
+public:
+    explicit ForwardingManager(HipSEPAIHRDParameterManager& inner) : in_(inner) {}
+    Eigen::VectorXd getCurrentParameters() const override { return in_.getCurrentParameters(); }
+    void updateModelParameters(const Eigen::VectorXd& p) override { in_.updateModelParameters(p); }
+    const std::vector<std::string>& getParameterNames() const override { return in_.getParameterNames(); }
+    size_t getParameterCount() const override { return in_.getParameterCount(); }
+    double getSigmaForParamIndex(int i) const override { return in_.getSigmaForParamIndex(i); }
+    Eigen::VectorXd applyConstraints(const Eigen::VectorXd& p) const override { return in_.applyConstraints(p); }
+    int getIndexForParam(const std::string& n) const override { return in_.getIndexForParam(n); }
+    double getLowerBoundForParamIndex(int i) const override { return in_.getLowerBoundForParamIndex(i); }
+    double getUpperBoundForParamIndex(int i) const override { return in_.getUpperBoundForParamIndex(i); }
+    void setMode(ConstraintMode m) { in_.setConstraintMode(m); }
+private:
+    HipSEPAIHRDParameterManager& in_;
+};
+}  // namespace
+
+extern "C" int host_reference_constructors(const sepaihrd_problem* pb, const char* names, const char* npi_names,
+                                           const double* sigmas, const double* thetas, int B, double* values,
+                                           double* model_back) {
+    try {
+        const int n = pb->n_age;
+        SEPAIHRDParameters mp;
+        mp.N = vec(pb->N, n);
+        mp.M_baseline = Eigen::MatrixXd(n, n);
+        std::memcpy(mp.M_baseline.data(), pb->M, sizeof(double) * n * n);
+        mp.a = vec(pb->a, n); mp.h_infec = vec(pb->h_infec, n); mp.p = vec(pb->p, n); mp.h = vec(pb->h, n);
+        mp.icu = vec(pb->icu, n); mp.d_H = vec(pb->d_H, n); mp.d_ICU = vec(pb->d_ICU, n);
+        mp.d_community = vec(pb->d_community, n);
+        mp.beta = pb->beta; mp.theta = pb->theta; mp.sigma = pb->sigma; mp.gamma_p = pb->gamma_p;
+        mp.gamma_A = pb->gamma_A; mp.gamma_I = pb->gamma_I; mp.gamma_H = pb->gamma_H; mp.gamma_ICU = pb->gamma_ICU;
+        mp.beta_end_times.assign(pb->beta_end_times, pb->beta_end_times + pb->n_beta);
+        mp.beta_values.assign(pb->beta_values, pb->beta_values + pb->n_beta);
+        mp.E0_multiplier = pb->multipliers[0]; mp.P0_multiplier = pb->multipliers[1];
+        mp.A0_multiplier = pb->multipliers[2]; mp.I0_multiplier = pb->multipliers[3];
+        mp.H0_multiplier = pb->multipliers[4]; mp.ICU0_multiplier = pb->multipliers[5];
+        mp.R0_multiplier = pb->multipliers[6]; mp.D0_multiplier = pb->multipliers[7];
+        mp.runup_days = pb->runup_days; mp.seed_exposed = pb->seed_exposed;
+        const std::vector<std::string> nm = split_lines(names);
+        std::map<std::string, double> sg;
+        std::map<std::string, std::pair<double, double>> bd;
+        for (size_t i = 0; i < nm.size(); ++i) {
+            sg[nm[i]] = sigmas[i];
+            bd[nm[i]] = {pb->lower[i], pb->upper[i]};
+        }
+        // main.cpp:222-242: the strategy takes the schedule after the baseline period
+        auto npi = std::make_shared<PiecewiseConstantNpiStrategy>(
+            std::vector<double>(pb->kappa_end_times + 1, pb->kappa_end_times + pb->n_kappa),
+            std::vector<double>(pb->kappa_values + 1, pb->kappa_values + pb->n_kappa),
+            std::map<std::string, std::pair<double, double>>{}, pb->kappa_values[0], pb->kappa_end_times[0], true,
+            split_lines(npi_names));
+        auto model = std::make_shared<AgeSEPAIHRDModel>(mp, npi);
+        auto mat = [&](const double* src) {
+            Eigen::MatrixXd m(pb->n_obs, n);
+            for (int r = 0; r < pb->n_obs; ++r)
+                for (int c = 0; c < n; ++c) m(r, c) = src[static_cast<size_t>(r) * n + c];
+            return m;
+        };
+        const CalibrationData data(mat(pb->obs_H), mat(pb->obs_ICU), mat(pb->obs_D), mp.N);
+        std::shared_ptr<IOdeSolverStrategy> solver;
+        if (pb->solver == SEPAIHRD_SOLVER_CASH_KARP54) solver = std::make_shared<CashKarpSolverStrategy>();
+        else solver = std::make_shared<Dopri5SolverStrategy>();
+        const std::vector<double> times(pb->times, pb->times + pb->n_times);
+        const Eigen::VectorXd x0 = vec(pb->initial_state, 11 * n);
+        const size_t P = nm.size();
+
+        // (a) the two make_unique calls of setupCalibrator with the class names changed
+        auto pm = std::make_unique<HipSEPAIHRDParameterManager>(model, nm, sg, bd);
+        SimulationCache cache_a(4);
+        auto objective = std::make_unique<HipSEPAIHRDObjectiveFunction>(model, *pm, cache_a, data, times, x0, solver,
+                                                                         pb->abs_err, pb->rel_err);
+        // (b) a manager of another type, mode changed without telling the objective
+        HipSEPAIHRDParameterManager inner(model->getModelParameters(), nm, sg, bd, split_lines(npi_names));
+        ForwardingManager foreign(inner);
+        SimulationCache cache_b(4);
+        HipSEPAIHRDObjectiveFunction objective_b(model, foreign, cache_b, data, times, x0, solver, pb->abs_err, pb->rel_err);
+        for (int mode = 0; mode < 2; ++mode) {
+            const ConstraintMode m = mode ? ConstraintMode::MCMC_REFLECT : ConstraintMode::OPTIMIZATION_CLAMP;
+            pm->setConstraintMode(m);
+            foreign.setMode(m);
+            for (int b = 0; b < B; ++b) {
+                const Eigen::VectorXd th = vec(thetas + static_cast<size_t>(b) * P, static_cast<int>(P));
+                cache_a.clear();
+                cache_b.clear();
+                values[(0 * 2 + mode) * static_cast<size_t>(B) + b] = objective->calculate(th);
+                values[(1 * 2 + mode) * static_cast<size_t>(B) + b] = objective_b.calculate(th);
+            }
+        }
+        pm->setConstraintMode(ConstraintMode::OPTIMIZATION_CLAMP);
+        pm->updateModelParameters(vec(thetas, static_cast<int>(P)));
+        HipSEPAIHRDParameterManager readback(model, nm, sg, bd);  // reads the model the first manager wrote into
+        const Eigen::VectorXd cur = readback.getCurrentParameters();
+        for (size_t i = 0; i < P; ++i) model_back[i] = cur[static_cast<Eigen::Index>(i)];
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// Model-side holders without a device: kappa(t) of PiecewiseConstantNpiStrategy at nt times; the model's
+// getModelParameters() schedule (baseline first), state size and first / last state names.
+extern "C" int host_model_holders(const double* ends_after, const double* values_after, int n_after, double baseline,
+                                  double baseline_end, const double* t, int nt, double* kappa_out, double* sched_ends,
+                                  double* sched_values, int* state_size, char* first_last, int first_last_len) {
+    try {
+        auto npi = std::make_shared<PiecewiseConstantNpiStrategy>(std::vector<double>(ends_after, ends_after + n_after),
+                                                                   std::vector<double>(values_after, values_after + n_after),
+                                                                   std::map<std::string, std::pair<double, double>>{}, baseline,
+                                                                   baseline_end);
+        for (int i = 0; i < nt; ++i) kappa_out[i] = npi->getReductionFactor(t[i]);
+        SEPAIHRDParameters mp;
+        const int n = 3;
+        mp.N = Eigen::VectorXd::Constant(n, 1000.0);
+        mp.M_baseline = Eigen::MatrixXd::Identity(n, n);
+        for (Eigen::VectorXd* v : {&mp.a, &mp.h_infec, &mp.p, &mp.h, &mp.icu, &mp.d_H, &mp.d_ICU}) *v = Eigen::VectorXd::Constant(n, 0.1);
+        AgeSEPAIHRDModel model(mp, npi);
+        const SEPAIHRDParameters back = model.getModelParameters();
+        for (size_t k = 0; k < back.kappa_values.size(); ++k) { sched_ends[k] = back.kappa_end_times[k]; sched_values[k] = back.kappa_values[k]; }
+        *state_size = model.getStateSize();
+        const std::vector<std::string> names = model.getStateNames();
+        std::snprintf(first_last, static_cast<size_t>(first_last_len), "%s %s %s %d", names.front().c_str(), names.back().c_str(),
+                      npi->getNpiParamName(0).c_str(), static_cast<int>(model.clone()->getNumAgeClasses()));
+        bool threw = false;
+        try {
+            std::vector<double> x(33, 0.0), dx(33, 0.0);
+            model.computeDerivatives(x, dx, 0.0);
+        } catch (const SimulationException&) { threw = true; }
+        return threw ? 0 : 2;  // there is no host right-hand side
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}

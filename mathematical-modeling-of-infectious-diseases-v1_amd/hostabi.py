@@ -32,6 +32,9 @@ def load_library() -> C.CDLL:
     lib.host_objective_create.argtypes = [C.POINTER(hipabi.sepaihrd_problem), C.c_char_p, C.c_char_p, vp, C.c_int,
                                           C.c_int, C.c_int]
     lib.host_objective_destroy.argtypes = [vp]
+    lib.host_model_holders.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_int),
+                                       C.c_char_p, C.c_int]
+    lib.host_reference_constructors.argtypes = [C.POINTER(hipabi.sepaihrd_problem), C.c_char_p, C.c_char_p, vp, vp, C.c_int, vp, vp]
     lib.host_objective_calculate.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.host_objective_calculate_batch.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.host_cache_stats.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -301,3 +304,39 @@ def metropolis_hastings_groups(objectives, initial, seed: int, iterations: int, 
     if rc:
         raise RuntimeError(lib.host_last_error().decode())
     return {"accepted": accepted, "best_value": best_value, "best": best, "accept_trace": trace[:, :iterations - 1]}
+
+
+def reference_constructors(pb, thetas) -> dict:
+    """The objective and the parameter manager built with the REFERENCE's constructor argument lists
+    (model first; SEPAIHRDModelCalibration.cpp:84-118): values[manager][mode][b] of calculate() for a Hip manager
+    built from the model and for a manager of another type, and the calibrated entries read back from the model
+    after updateModelParameters(thetas[0])."""
+    lib = load_library()
+    keep: list = []
+    st = hipabi.build_problem_struct(pb, keep)
+    sig = np.ascontiguousarray(pb.sigma_array())
+    th = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+    B, P = th.shape
+    values = np.empty((2, 2, B))
+    back = np.empty(P)
+    if lib.host_reference_constructors(C.byref(st), "\n".join(pb.param_names).encode(), "\n".join(pb.npi_names).encode(),
+                                       sig.ctypes.data, th.ctypes.data, B, values.ctypes.data, back.ctypes.data):
+        raise RuntimeError("host_reference_constructors: " + lib.host_last_error().decode())
+    return {"values": values, "model_back": back}
+
+
+def model_holders(ends_after, values_after, baseline, baseline_end, t) -> dict:
+    """PiecewiseConstantNpiStrategy::getReductionFactor at times t and what AgeSEPAIHRDModel reports (no device)."""
+    lib = load_library()
+    ea = np.ascontiguousarray(ends_after, dtype=np.float64)
+    va = np.ascontiguousarray(values_after, dtype=np.float64)
+    tt = np.ascontiguousarray(t, dtype=np.float64)
+    kap = np.empty(len(tt))
+    se, sv = np.empty(len(ea) + 1), np.empty(len(ea) + 1)
+    size = C.c_int()
+    buf = C.create_string_buffer(128)
+    rc = lib.host_model_holders(ea.ctypes.data, va.ctypes.data, len(ea), baseline, baseline_end, tt.ctypes.data, len(tt),
+                                kap.ctypes.data, se.ctypes.data, sv.ctypes.data, C.byref(size), buf, len(buf))
+    if rc:
+        raise RuntimeError("host_model_holders: rc %d %s" % (rc, lib.host_last_error().decode()))
+    return {"kappa": kap, "schedule_ends": se, "schedule_values": sv, "state_size": size.value, "names": buf.value.decode()}

@@ -335,3 +335,27 @@ def test_device_sampler_accept_traces_in_production_arithmetic(mm, oracle_py, sy
         assert np.array_equal(dev["samples"][c], ref["samples"])
         np.testing.assert_allclose(dev["sample_values"][c], ref["sample_values"], rtol=1e-7)
         np.testing.assert_allclose(dev["final_scale"][c], ref["final_scale"], rtol=1e-14)
+
+
+def test_reference_constructor_argument_lists(mm, shipped):
+    """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
+    objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,
+    SEPAIHRDObjectiveFunction.hpp:49-58).  Same values as the struct-taking constructors in both constraint modes --
+    with a HipSEPAIHRDParameterManager, and with an IParameterManager of another type whose mode is switched
+    without telling the objective (what ModelCalibrator.cpp:62-64,88-90 does to the reference's own manager);
+    updateModelParameters() writes into the model it was given."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT)
+    rs = np.random.RandomState(4)
+    lo, hi, _ = pb.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(-0.2, 1.2, (5, pb.n_params))   # beyond the bounds: the mode matters
+    theta[0] = pb.base_theta
+    theta[0, 3] = hi[3] + 0.3 * (hi[3] - lo[3])
+    got = mm.hostabi.reference_constructors(pb, theta)
+    for mode in (0, 1):
+        want, status = mm.HostObjective(pb.with_(constraint_mode=mode)).calculate_batch(theta)
+        assert np.all(status <= 1)
+        assert np.array_equal(got["values"][0, mode], want), mode
+        assert np.array_equal(got["values"][1, mode], want), mode
+    assert not np.array_equal(got["values"][0, 0], got["values"][0, 1])
+    clamped = mm.HostObjective(pb, with_objective=False).apply_constraints(theta[0], 0)[0]
+    assert np.array_equal(got["model_back"], clamped)

@@ -293,3 +293,19 @@ def test_compute_entry_points_refuse_to_run_without_a_device(mm, shipped, have_g
         pytest.skip("a GPU is present: covered by the -m gpu suite")
     with pytest.raises(RuntimeError, match="(?i)device|hip"):
         mm.HipObjective(shipped)
+
+
+def test_model_side_holders_follow_the_reference(mm, oracle_py, shipped):
+    """AgeSEPAIHRDModel / PiecewiseConstantNpiStrategy as the reference's constructors take them (host only):
+    kappa(t) with the reference's rules -- baseline for t < 0 and t <= baseline end, `t <= end` keeps the OLD value at a
+    breakpoint, the last value for ever (PieceWiseConstantNPIStrategy.cpp:86-127) -- equal to the oracle's restatement;
+    getModelParameters() carries the schedule baseline first (AgeSEPAIHRDModel.cpp:294-323); there is no host RHS."""
+    ends, vals = np.asarray(shipped.kappa_end_times), np.asarray(shipped.kappa_values)
+    t = np.concatenate([[-20.0, -0.5, 0.0], ends - 1e-9, ends, ends + 1e-9, [1e4]])
+    got = mm.hostabi.model_holders(ends[1:], vals[1:], vals[0], ends[0], t)
+    orc = oracle_py.Oracle(shipped)
+    want = np.array([orc.beta_kappa(x)[1] for x in t])
+    assert np.array_equal(got["kappa"], want)
+    assert got["kappa"][0] == vals[0] and got["kappa"][-1] == vals[-1]
+    assert np.array_equal(got["schedule_ends"], ends) and np.array_equal(got["schedule_values"], vals)
+    assert got["state_size"] == 33 and got["names"] == "S0 CumICU2 kappa_2 3"
