@@ -277,13 +277,18 @@ def main():
     hip.set_arith(pb.arith)
 
     allgather_ms = None
-    if args.allgather and world > 1 and not rehearsal:
+    allgather_check = None
+    if args.allgather and world > 1:
         # post-calibration ensemble summary record per chain: [P means | P variances |
-        # best logpost | accept count] -- here filled with the chain's theta and log-likelihood
+        # best logpost | accept count] -- here filled with the chain's theta and log-likelihood.
+        # RCCL over xGMI on GPUs; in the rehearsal (every rank on one GPU) the same call over gloo on host copies
         rec = torch.zeros(B, 2 * P + 2, dtype=torch.float64, device=dev)
         rec[:, :P] = pools[(K - 1) % n_pool]
         rec[:, 2 * P] = d_ll
-        gathered = torch.empty(world * B, 2 * P + 2, dtype=torch.float64, device=dev)
+        rec[:, 2 * P + 1] = float(rank)
+        if rehearsal:
+            rec = rec.cpu()
+        gathered = torch.empty(world * B, 2 * P + 2, dtype=torch.float64, device=rec.device)
         dist.all_gather_into_tensor(gathered, rec)
         torch.cuda.synchronize(dev)
         dist.barrier()
@@ -291,6 +296,10 @@ def main():
         dist.all_gather_into_tensor(gathered, rec)
         torch.cuda.synchronize(dev)
         allgather_ms = (time.perf_counter() - t1) * 1e3
+        # every rank's block sits at its rank offset and this rank's own block came back unchanged
+        owners = gathered[:, 2 * P + 1].reshape(world, B)
+        allgather_check = bool(torch.equal(owners, torch.arange(world, dtype=torch.float64, device=rec.device)[:, None].expand(world, B))
+                               and torch.equal(gathered[rank * B:(rank + 1) * B], rec))
 
     if rank == 0:
         evals_total = world * B * K
@@ -363,6 +372,11 @@ def main():
         }
         if allgather_ms is not None:
             out["allgather_ms"] = allgather_ms
+            out["allgather"] = {"ms": allgather_ms, "bytes_per_rank": B * (2 * P + 2) * 8, "ranks": world,
+                                "backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL)",
+                                "blocks_in_rank_order": allgather_check}
+        if rehearsal:
+            out["rehearsal"] = True  # not a measurement: every rank shares device 0
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pb, pools_host[0], args.cpu_seconds)
         else:

@@ -17,6 +17,7 @@ Reference behaviour followed (paths under /root/reference):
 from __future__ import annotations
 
 import csv
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -206,3 +207,145 @@ def write_posterior_trace_csv(path: str, samples: np.ndarray, values: np.ndarray
         fh.write("iter,log_posterior" + "".join("," + n for n in names) + "\n")
         for i in range(len(values)):
             fh.write(str(i) + "," + "%.6e" % values[i] + "".join(",%.6e" % v for v in samples[i]) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Post-calibration output tree, in the layout and column names the reference writes and its plotting script reads
+#   writer    src/model/AnalysisWriter.cpp:201-283 (parameter posteriors), :285-345 (posterior predictive),
+#             :349-398 (batch metrics), :400-437 (metrics summary), :512-540 (aggregated trajectories)
+#   layout    src/model/PostCalibrationAnalyser.cpp:64-90,253,283-343
+#   consumer  scripts/model/PostCalibrationAnalysis.py:98-133,169-170,216,271,322,358
+# ---------------------------------------------------------------------------------------------------------------
+PPC_SERIES = ["daily_hospitalizations", "daily_icu_admissions", "daily_deaths", "cumulative_hospitalizations",
+              "cumulative_icu_admissions", "cumulative_deaths"]
+PPC_PROBS = [0.025, 0.05, 0.5, 0.95, 0.975]           # lower95, lower90, median, upper90, upper95
+_PPC_SUFFIX = ["lower95", "lower90", "median", "upper90", "upper95"]
+ESSENTIAL_METRICS = ["R0", "overall_IFR", "overall_attack_rate", "peak_hospital", "peak_ICU", "time_to_peak_hospital",
+                     "time_to_peak_ICU", "total_deaths", "max_Rt", "min_Rt", "final_Rt", "seroprevalence_day64"]
+
+
+def _cxx_default(v: float) -> str:
+    """operator<<(double) with the stream defaults (%g, 6 significant digits): how the reference prints times."""
+    return "%g" % v
+
+
+def _quantile_sorted(values: np.ndarray, q: float) -> float:
+    pos = q * (len(values) - 1)                       # PostCalibrationAnalyser.cpp:316-326
+    idx = int(pos)
+    frac = pos - idx
+    return float(values[idx] * (1.0 - frac) + values[idx + 1] * frac) if idx + 1 < len(values) else float(values[idx])
+
+
+def write_posterior_predictive(out_dir: str, times_pos, ppc: np.ndarray, observed: Dict[str, np.ndarray]) -> List[str]:
+    """posterior_predictive/<series>_{median,lower90,upper90,lower95,upper95,observed}.csv: ``time,age_0,...`` and
+    ``std::fixed << setprecision(6)`` values.  ppc: [6 series][5 PPC_PROBS][T_pos][n]; observed: series -> [T_pos][n]
+    (series without an entry get no _observed file)."""
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    n = ppc.shape[3]
+    header = "time" + "".join(f",age_{a}" for a in range(n)) + "\n"
+
+    def dump(path, mat):
+        with open(path, "w") as fh:
+            fh.write(header)
+            for ti, t in enumerate(times_pos):
+                fh.write(_cxx_default(t) + "".join(",%.6f" % mat[ti, a] for a in range(n)) + "\n")
+        written.append(path)
+
+    for si, name in enumerate(PPC_SERIES):
+        for pi, suffix in enumerate(_PPC_SUFFIX):
+            dump(os.path.join(out_dir, f"{name}_{suffix}.csv"), ppc[si, pi])
+        if name in observed:
+            dump(os.path.join(out_dir, f"{name}_observed.csv"), np.asarray(observed[name])[:len(times_pos)])
+    return written
+
+
+def write_aggregated_trajectory(path: str, times, quantiles: np.ndarray) -> None:
+    """rt_trajectories/Rt_aggregated_with_uncertainty.csv, seroprevalence/seroprevalence_trajectory.csv:
+    ``time,median,q025,q975,q05,q95`` fixed 6 digits.  quantiles: [5 PPC_PROBS][T]."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    q025, q05, med, q95, q975 = quantiles
+    with open(path, "w") as fh:
+        fh.write("time,median,q025,q975,q05,q95\n")
+        for ti, t in enumerate(times):
+            fh.write("%.6f,%.6f,%.6f,%.6f,%.6f,%.6f\n" % (t, med[ti], q025[ti], q975[ti], q05[ti], q95[ti]))
+
+
+def write_parameter_posteriors(out_dir: str, samples: np.ndarray, names: List[str], burn_in: int = 0, thinning: int = 1) -> None:
+    """parameter_posteriors/posterior_samples.csv (``sample_index,<names>``, scientific 8 digits, rows burn_in,
+    burn_in + thinning, ...) and posterior_summary.csv (``parameter,mean,median,std_dev,lower_95_ci,upper_95_ci``,
+    fixed 8 digits; median = sorted[n/2], bounds = sorted[int(q n)], population std: the writer's own rules)."""
+    os.makedirs(out_dir, exist_ok=True)
+    kept = np.asarray(samples)[burn_in::max(1, thinning)]
+    with open(os.path.join(out_dir, "posterior_samples.csv"), "w") as fh:
+        fh.write("sample_index" + "".join("," + nm for nm in names) + "\n")
+        for i, row in enumerate(kept):
+            fh.write(str(i) + "".join(",%.8e" % v for v in row) + "\n")
+    with open(os.path.join(out_dir, "posterior_summary.csv"), "w") as fh:
+        fh.write("parameter,mean,median,std_dev,lower_95_ci,upper_95_ci\n")
+        for p, nm in enumerate(names):
+            v = np.sort(kept[:, p])
+            if len(v) == 0:
+                continue
+            mean = float(np.sum(v) / len(v))
+            std = float(np.sqrt(np.sum((v - mean) ** 2) / len(v)))
+            fh.write("%s,%.8f,%.8f,%.8f,%.8f,%.8f\n" % (nm, mean, v[len(v) // 2], std, v[int(0.025 * len(v))],
+                                                        v[min(int(0.975 * len(v)), len(v) - 1)]))
+
+
+def essential_metric_columns(n_age: int) -> List[str]:
+    return ESSENTIAL_METRICS + [f"{m}_age_{a}" for a in range(n_age) for m in ("IFR", "IHR", "IICUR", "AttackRate")]
+
+
+def write_batch_metrics(path: str, metrics: np.ndarray, n_age: int, kappa: Dict[str, np.ndarray] | None = None) -> None:
+    """mcmc_batches/batch_k.csv: ``sample_idx,R0,...,seroprevalence_day64,IFR_age_0,IHR_age_0,IICUR_age_0,
+    AttackRate_age_0,...[,kappa_1,...]``, values with the stream defaults.  metrics: [S][12 + 4 n] as
+    sepaihrd_ensemble_quantiles returns them; NaN rows (skipped samples) are left out like the reference's
+    ``if (!sim_result.isValid()) continue``."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    cols = essential_metric_columns(n_age)
+    kappa = kappa or {}
+    with open(path, "w") as fh:
+        fh.write("sample_idx," + ",".join(cols + list(kappa)) + "\n")
+        i = 0
+        for s, row in enumerate(np.asarray(metrics)):
+            if not np.all(np.isfinite(row[:1])):
+                continue
+            fh.write(str(i) + "".join("," + _cxx_default(v) for v in row) +
+                     "".join("," + _cxx_default(kappa[k][s]) for k in kappa) + "\n")
+            i += 1
+
+
+def write_metrics_summary(path: str, metrics: np.ndarray, n_age: int) -> None:
+    """mcmc_aggregated/metrics_summary.csv: ``metric,mean,median,std_dev,q025,q975`` fixed 8 digits, one row per
+    metric in map (alphabetical) order -- the index the plotting script looks ``IFR_age_j`` up in.  Exact
+    sort-based quantiles over the valid rows (the reference pools per-batch P-square estimates)."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    m = np.asarray(metrics)
+    m = m[np.isfinite(m[:, 0])]
+    cols = essential_metric_columns(n_age)
+    with open(path, "w") as fh:
+        fh.write("metric,mean,median,std_dev,q025,q975\n")
+        for name in sorted(cols):
+            v = np.sort(m[:, cols.index(name)])
+            if len(v) == 0:
+                continue
+            mean = float(np.mean(v))
+            fh.write("%s,%.8f,%.8f,%.8f,%.8f,%.8f\n" % (name, mean, _quantile_sorted(v, 0.5), float(np.sqrt(np.mean((v - mean) ** 2))),
+                                                        _quantile_sorted(v, 0.025), _quantile_sorted(v, 0.975)))
+
+
+def write_post_calibration_tree(out_base: str, times, ensemble: dict, samples: np.ndarray, names: List[str], n_age: int,
+                                observed: Dict[str, np.ndarray] | None = None, burn_in: int = 0, thinning: int = 1) -> None:
+    """Everything PostCalibrationAnalysis.py loads (except the scenario comparison, which is not on this path), under
+    out_base, from one sepaihrd_ensemble_quantiles result (keys ppc, sero, rt, metrics; quantiles at PPC_PROBS)."""
+    times = np.asarray(times, dtype=np.float64)
+    write_posterior_predictive(os.path.join(out_base, "posterior_predictive"), times[times >= 0], ensemble["ppc"], observed or {})
+    write_parameter_posteriors(os.path.join(out_base, "parameter_posteriors"), samples, names, burn_in, thinning)
+    if ensemble.get("rt") is not None:
+        write_aggregated_trajectory(os.path.join(out_base, "rt_trajectories", "Rt_aggregated_with_uncertainty.csv"), times, ensemble["rt"])
+    if ensemble.get("sero") is not None:
+        write_aggregated_trajectory(os.path.join(out_base, "seroprevalence", "seroprevalence_trajectory.csv"), times, ensemble["sero"])
+    if ensemble.get("metrics") is not None:
+        write_batch_metrics(os.path.join(out_base, "mcmc_batches", "batch_0.csv"), ensemble["metrics"], n_age)
+        write_metrics_summary(os.path.join(out_base, "mcmc_aggregated", "metrics_summary.csv"), ensemble["metrics"], n_age)

@@ -3,7 +3,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <limits>
+#include <stdexcept>
+#include <string>
 
 namespace epidemic {
 
@@ -11,62 +14,54 @@ namespace {
 inline double clampd(double v, double lo, double hi) { return std::clamp(v, lo, hi); }
 }  // namespace
 
+// Settings arrive as one key -> double map (pso_settings.txt).  Each known key is a row of the table below: where
+// the value goes and the range it must lie in -- the same keys and the same accept / reject decisions as
+// ParticleSwarmOptimization::configure (ParticleSwarmOptimizer.cpp:10-95); unknown keys are ignored like there
+// (use_parallel and log_evolutionary_state have nothing to switch on this path).
 void BatchedParticleSwarmOptimization::configure(const std::map<std::string, double>& settings) {
-    for (const auto& [key, value] : settings) {  // :15-84, same checks
-        if (key == "iterations") {
-            if (value <= 0) throw std::invalid_argument("iterations must be positive");
-            iterations_ = static_cast<int>(value);
-        } else if (key == "swarm_size") {
-            if (value <= 0) throw std::invalid_argument("swarm_size must be positive");
-            swarm_size_ = static_cast<int>(value);
-        } else if (key == "omega_start") {
-            if (value < 0) throw std::invalid_argument("omega_start must be non-negative");
-            omega_start_ = value;
-        } else if (key == "omega_end") {
-            if (value < 0) throw std::invalid_argument("omega_end must be non-negative");
-            omega_end_ = value;
-        } else if (key == "c1_initial") {
-            if (value < 0) throw std::invalid_argument("c1_initial must be non-negative");
-            c1_initial_ = value;
-        } else if (key == "c1_final") {
-            if (value < 0) throw std::invalid_argument("c1_final must be non-negative");
-            c1_final_ = value;
-        } else if (key == "c2_initial") {
-            if (value < 0) throw std::invalid_argument("c2_initial must be non-negative");
-            c2_initial_ = value;
-        } else if (key == "c2_final") {
-            if (value < 0) throw std::invalid_argument("c2_final must be non-negative");
-            c2_final_ = value;
-        } else if (key == "report_interval") {
-            if (value <= 0) throw std::invalid_argument("report_interval must be positive");
-            report_interval_ = static_cast<int>(value);
-        } else if (key == "variant") {
-            const int v = static_cast<int>(value);
-            if (v < 0 || v > 4) throw std::invalid_argument("variant must be between 0 and 4");
-            variant_ = static_cast<PSOVariant>(v);
-        } else if (key == "topology") {
-            const int t = static_cast<int>(value);
-            if (t < 0 || t > 3) throw std::invalid_argument("topology must be between 0 and 3");
-            topology_ = static_cast<TopologyType>(t);
-        } else if (key == "use_opposition_learning") {
-            use_opposition_learning_ = (value != 0.0);
-        } else if (key == "use_adaptive_parameters") {
-            use_adaptive_parameters_ = (value != 0.0);
-        } else if (key == "diversity_threshold") {
-            diversity_threshold_ = value;
-        } else if (key == "restart_threshold") {
-            restart_threshold_ = value;
-        } else if (key == "quantum_beta") {
-            quantum_beta_ = value;
-        } else if (key == "levy_alpha") {
-            levy_alpha_ = value;
-        } else if (key == "max_stagnation") {
-            if (value <= 0) throw std::invalid_argument("max_stagnation must be positive");
-            max_stagnation_ = static_cast<int>(value);
-        } else if (key == "seed") {
-            seed_ = static_cast<uint32_t>(value);
+    enum Range { ANY, POSITIVE, NON_NEGATIVE, ENUM_0_4, ENUM_0_3 };
+    struct Setting {
+        const char* key;
+        Range range;
+        std::function<void(double)> store;
+    };
+    auto as_int = [](int& dst) { return [&dst](double v) { dst = static_cast<int>(v); }; };
+    auto as_double = [](double& dst) { return [&dst](double v) { dst = v; }; };
+    auto as_flag = [](bool& dst) { return [&dst](double v) { dst = v != 0.0; }; };
+    const Setting table[] = {
+        {"iterations", POSITIVE, as_int(iterations_)},
+        {"swarm_size", POSITIVE, as_int(swarm_size_)},
+        {"report_interval", POSITIVE, as_int(report_interval_)},
+        {"max_stagnation", POSITIVE, as_int(max_stagnation_)},
+        {"omega_start", NON_NEGATIVE, as_double(omega_start_)},
+        {"omega_end", NON_NEGATIVE, as_double(omega_end_)},
+        {"c1_initial", NON_NEGATIVE, as_double(c1_initial_)},
+        {"c1_final", NON_NEGATIVE, as_double(c1_final_)},
+        {"c2_initial", NON_NEGATIVE, as_double(c2_initial_)},
+        {"c2_final", NON_NEGATIVE, as_double(c2_final_)},
+        {"variant", ENUM_0_4, [this](double v) { variant_ = static_cast<PSOVariant>(static_cast<int>(v)); }},
+        {"topology", ENUM_0_3, [this](double v) { topology_ = static_cast<TopologyType>(static_cast<int>(v)); }},
+        {"use_opposition_learning", ANY, as_flag(use_opposition_learning_)},
+        {"use_adaptive_parameters", ANY, as_flag(use_adaptive_parameters_)},
+        {"diversity_threshold", ANY, as_double(diversity_threshold_)},
+        {"restart_threshold", ANY, as_double(restart_threshold_)},
+        {"quantum_beta", ANY, as_double(quantum_beta_)},
+        {"levy_alpha", ANY, as_double(levy_alpha_)},
+        {"seed", ANY, [this](double v) { seed_ = static_cast<uint32_t>(v); }},  // build-side: replaces std::random_device (:578)
+    };
+    for (const Setting& row : table) {
+        const auto it = settings.find(row.key);
+        if (it == settings.end()) continue;
+        const double v = it->second;
+        const int whole = static_cast<int>(v);
+        const bool ok = row.range == ANY || (row.range == POSITIVE && v > 0) || (row.range == NON_NEGATIVE && v >= 0) ||
+                        (row.range == ENUM_0_4 && whole >= 0 && whole <= 4) || (row.range == ENUM_0_3 && whole >= 0 && whole <= 3);
+        if (!ok) {
+            static const char* what[] = {"", "a positive number", "zero or a positive number", "one of 0..4", "one of 0..3"};
+            throw std::invalid_argument(std::string("particle swarm setting '") + row.key + "' = " + std::to_string(v) +
+                                        ": expected " + what[row.range]);
         }
-        // use_parallel / log_evolutionary_state: accepted and irrelevant here
+        row.store(v);
     }
 }
 

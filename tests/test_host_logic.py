@@ -309,3 +309,60 @@ def test_model_side_holders_follow_the_reference(mm, oracle_py, shipped):
     assert got["kappa"][0] == vals[0] and got["kappa"][-1] == vals[-1]
     assert np.array_equal(got["schedule_ends"], ends) and np.array_equal(got["schedule_values"], vals)
     assert got["state_size"] == 33 and got["names"] == "S0 CumICU2 kappa_2 3"
+
+
+def test_post_calibration_tree_matches_the_reference_writers_and_its_plot_script(mm, tmp_path):
+    """the files after the path.  The tree config_io writes from one ensemble result has the file names,
+    headers and number formats of the reference's AnalysisWriter / MetropolisHastingsSampler writers (expected headers
+    committed in tests/golden/reference_output_headers.json) and loads the way scripts/model/PostCalibrationAnalysis.py
+    loads it (pandas read_csv, 'time' -> date, 'age_' columns, metrics summary indexed by metric name)."""
+    import json
+    import pandas as pd
+    from mmid_amd import config_io as cio
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_output_headers.json")) as fh:
+        want = json.load(fh)
+    rs = np.random.RandomState(0)
+    n, T, S = 4, 30, 50
+    times = np.arange(-5, T - 5, dtype=np.float64)
+    Tp = int(np.sum(times >= 0))
+    q = np.sort(rs.gamma(2.0, 10.0, (6, 5, Tp, n)), axis=1)
+    metrics = rs.uniform(0.001, 2.0, (S, 12 + 4 * n))
+    metrics[7] = np.nan                                      # a skipped sample
+    ens = {"ppc": q, "rt": np.sort(rs.uniform(0.5, 3, (5, T)), axis=0), "sero": np.sort(rs.uniform(0, 0.2, (5, T)), axis=0),
+           "metrics": metrics}
+    samples = rs.normal(size=(S, 2)) * [1e-3, 1e4]
+    obs = {name: rs.poisson(5.0, (Tp, n)).astype(float) for name in cio.PPC_SERIES}
+    out = str(tmp_path / "post")
+    cio.write_post_calibration_tree(out, times, ens, samples, ["p0", "p1"], n, observed=obs, burn_in=10, thinning=2)
+    for rel, header in want["files"].items():
+        path = os.path.join(out, rel)
+        assert os.path.exists(path), rel
+        with open(path) as fh:
+            assert fh.readline().rstrip("\n").split(",") == header, rel
+    # number formats: fixed 6 in the predictive files, scientific 8 in the samples, fixed 8 in the summaries
+    line = open(os.path.join(out, "posterior_predictive", "daily_deaths_median.csv")).readlines()[1].rstrip().split(",")
+    assert line[0] == "0" and all(len(v.split(".")[1]) == 6 for v in line[1:])
+    line = open(os.path.join(out, "parameter_posteriors", "posterior_samples.csv")).readlines()[1].rstrip().split(",")
+    assert line[0] == "0" and all("e" in v and len(v.split("e")[0].split(".")[1]) == 8 for v in line[1:])
+    assert len(open(os.path.join(out, "parameter_posteriors", "posterior_samples.csv")).readlines()) == 1 + len(range(10, S, 2))
+    assert len(open(os.path.join(out, "mcmc_batches", "batch_0.csv")).readlines()) == 1 + S - 1   # the NaN row is skipped
+    # ... and the plotting script's own access pattern (PostCalibrationAnalysis.py:64-76,98-121,175-176,216-241,322-337)
+    med = pd.read_csv(os.path.join(out, "posterior_predictive", "daily_hospitalizations_median.csv"))
+    assert "time" in med.columns and [c for c in med.columns if "age_" in c] == [f"age_{a}" for a in range(n)]
+    date = pd.to_datetime("2020-03-01") + pd.to_timedelta(med["time"], unit="D")
+    assert len(date) == Tp and np.allclose(med[[f"age_{a}" for a in range(n)]].sum(axis=1), q[0, 2].sum(axis=1), atol=1e-5)
+    summ = pd.read_csv(os.path.join(out, "mcmc_aggregated", "metrics_summary.csv"), index_col=0)
+    for prefix in ("IFR", "IHR", "IICUR"):
+        for j in range(n):
+            row = summ.loc[f"{prefix}_age_{j}"]
+            assert row["q025"] <= row["median"] <= row["q975"]
+    rt = pd.read_csv(os.path.join(out, "rt_trajectories", "Rt_aggregated_with_uncertainty.csv"))
+    assert np.all(rt["q025"] <= rt["median"]) and np.all(rt["q05"] <= rt["q95"]) and np.allclose(rt["median"], ens["rt"][2], atol=1e-6)
+    ps = pd.read_csv(os.path.join(out, "parameter_posteriors", "posterior_samples.csv"))
+    assert [p for p in ps.columns if p not in ["sample_index", "objective_value"]] == ["p0", "p1"]
+    # the sampler's own trace file (MetropolisHastingsSampler.cpp:414-438)
+    trace = str(tmp_path / "posterior_trace_final.csv")
+    cio.write_posterior_trace_csv(trace, samples[:3], np.array([-1.5e6, 2.0, 3.25e-3]), ["p0", "p1"])
+    lines = open(trace).read().splitlines()
+    assert lines[0].split(",") == want["posterior_trace"]["header"]
+    assert lines[1].split(",")[:2] == ["0", "-1.500000e+06"] and lines[3].split(",")[1] == "3.250000e-03"

@@ -65,3 +65,49 @@ def test_two_rank_gloo_allgather_matches_single_process(tmp_path, mm, oracle_py)
     g1 = np.load(tmp_path / "gathered_1.npy")
     assert np.array_equal(g0, want) and np.array_equal(g1, want)
     assert np.array_equal(np.load(tmp_path / "quant_0.npy"), np.load(tmp_path / "quant_1.npy"))
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_end_to_end():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank, --gpus 2
+    --allgather), rehearsed on ONE GPU: SEPAIHRD_BENCH_REHEARSAL=1 puts both ranks on device 0 and swaps RCCL for
+    gloo -- the sharded draws, barriers, max-over-ranks timing, the all-gather of the per-chain summary records
+    and the rank-0 JSON line are the production code.  Not a measurement (the line says so)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SEPAIHRD_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--allgather", "--chains", "1500", "--sampler-iterations", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["rehearsal"] is True and out["cpu_baseline"] is None
+    assert out["unit"] == "evals/s" and out["higher_is_better"] is True and out["dtype"] == "f64"
+    # whole-job aggregate: both ranks' chains over the max-over-ranks time
+    assert abs(out["value"] - 2 * 1500 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["status_counts"][0] == 1500
+    ag = out["allgather"]
+    assert ag["ranks"] == 2 and ag["blocks_in_rank_order"] is True and ag["bytes_per_rank"] == 1500 * (2 * 62 + 2) * 8
+    assert out["roofline"]["bound"] == "fp64_valu" and 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_chain_groups_on_distinct_devices(mm, oracle_py, shipped):
+    """optimizeChainGroupsOnDevice with one objective per DEVICE (how the C++ sampler shards over the GPUs of a
+    node: an objective is bound to a device at construction) == the single-device run.  Needs two visible GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the multi-device grouping needs two")
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    x0 = oracle_py.Oracle(pb).jitter_draws(pb.base_theta, 9, 7, mode=1)
+    kw = dict(seed=23, iterations=120, burn_in=40, adaptation_period=30, thinning=5)
+    one = mm.HostObjective(pb, device=0).metropolis_hastings(x0, device_state=True, **kw)
+    objs = [mm.HostObjective(pb, device=d) for d in range(2)]
+    grp = mm.hostabi.metropolis_hastings_groups(objs, x0, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best"):
+        assert np.array_equal(grp[k], one[k]), k

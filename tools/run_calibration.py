@@ -88,25 +88,14 @@ def main():
     t_ens = time.perf_counter() - t0
     times = np.asarray(pb.times)
     pos = times[times >= 0]
-    with open(os.path.join(args.out, "posterior_predictive_quantiles.csv"), "w", newline="") as fh:
-        w = csv.writer(fh)
-        w.writerow(["series", "time", "age_group", "q025", "q05", "median", "q95", "q975"])
-        for si, name in enumerate(SERIES):
-            for ti, t in enumerate(pos):
-                for a in range(pb.n):
-                    w.writerow([name, t, a] + [f"{ens['ppc'][si, p, ti, a]:.8e}" for p in range(5)])
-    for key, fname in (("sero", "seroprevalence_trajectory.csv"), ("rt", "Rt_aggregated_with_uncertainty.csv")):
-        with open(os.path.join(args.out, fname), "w", newline="") as fh:
-            w = csv.writer(fh)
-            w.writerow(["time", "q025", "q05", "median", "q95", "q975"])
-            for ti, t in enumerate(times):
-                w.writerow([t] + [f"{ens[key][p, ti]:.8e}" for p in range(5)])
-    cols = METRICS + [f"{m}_age_{a}" for a in range(pb.n) for m in ("IFR", "IHR", "IICUR", "AttackRate")]
-    with open(os.path.join(args.out, "essential_metrics.csv"), "w", newline="") as fh:
-        w = csv.writer(fh)
-        w.writerow(["sample"] + cols)
-        for s, row in enumerate(ens["metrics"]):
-            w.writerow([s] + [f"{v:.8e}" for v in row])
+    # the reference's post-calibration output tree (file names, headers and number formats of AnalysisWriter.cpp; what
+    # scripts/model/PostCalibrationAnalysis.py loads): posterior_predictive/, parameter_posteriors/, rt_trajectories/,
+    # seroprevalence/, mcmc_batches/, mcmc_aggregated/
+    observed = {"daily_hospitalizations": pb.obs_H, "daily_icu_admissions": pb.obs_ICU, "daily_deaths": pb.obs_D,
+                "cumulative_hospitalizations": np.cumsum(pb.obs_H, axis=0), "cumulative_icu_admissions": np.cumsum(pb.obs_ICU, axis=0),
+                "cumulative_deaths": np.cumsum(pb.obs_D, axis=0)}
+    mm.config_io.write_post_calibration_tree(args.out, times, ens, pooled, list(pb.param_names), pb.n, observed=observed)
+    assert len(pos) == ens["ppc"].shape[2]
 
     evals = args.chains * args.mcmc_iterations
     summary = {"initial_value": cal["initial_value"], "phase1_best_value": cal["phase1_best_value"],
