@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--arith", choices=["strict", "fma"], default="fma",
                     help="fma: mul+add contraction on (production mode, parity-tested to the 1e-6 north-star "
                          "tolerance); strict: the CPU build's operation sequence (bit-level parity mode)")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="number type of the ODE state: f64 = the reference's arithmetic (headline); f32 = the fp32-state arm "
+                         "of BASELINE configs[4]'s sweep (fp64 likelihood), 3..16 age classes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
     ap.add_argument("--sampler-iterations", type=int, default=400,
@@ -204,6 +207,7 @@ def main():
     solver_name = "dopri5" if pb.solver == mm.SOLVER_DOPRI5 else "cashkarp"
     pb.arith = mm.ARITH_STRICT if args.arith == "strict" else mm.ARITH_FMA
     pb.constraint_mode = mm.CONSTRAINT_REFLECT
+    pb.precision = mm.PRECISION_F32 if args.precision == "f32" else mm.PRECISION_F64
     B, K, W = (args.chains or workloads.DEFAULT_CHAINS[args.workload]), args.steps, args.warmup
     P = pb.n_params
 
@@ -260,6 +264,9 @@ def main():
 
     # the other arithmetic mode, same draws, reported next to the headline (not part of `value`)
     other = "strict" if args.arith == "fma" else "fma"
+    if args.precision == "f32":  # next to the fp32 arm: the fp64 production arithmetic on the same draws
+        other = "fma"
+        hip.set_precision(mm.PRECISION_F64)
     hip.set_arith(mm.ARITH_STRICT if other == "strict" else mm.ARITH_FMA)
     for i in range(max(1, W)):
         step(i)
@@ -275,6 +282,7 @@ def main():
     other_wall_ms = (time.perf_counter() - t_other) * 1e3 / n_other
     other_ms = e0.elapsed_time(e1) / n_other
     hip.set_arith(pb.arith)
+    hip.set_precision(pb.precision)
 
     allgather_ms = None
     allgather_check = None
@@ -309,7 +317,7 @@ def main():
         # csrc/sepaihrd_device.h split_likelihood(): batches that do not fill the chip, and Dopri5 in tolerance mode at
         # any size, park the daily increments for a separate likelihood pass
         waves4 = -(-B // (64 // max(1, 1 << (pb.n - 1).bit_length())))
-        split_ll = waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)
+        split_ll = (waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)) and args.precision == "f64"
         ws_bytes_eval = pb.n_times * 3 * pb.n * 8 if split_ll else 0
         bytes_launch = bytes_eval * B
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
@@ -329,13 +337,13 @@ def main():
             "metric": "ODE-solve+likelihood evals/sec (SEPAIHRD %d-age, %dd)" % (pb.n, int(pb.times[-1] - pb.times[0])),
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed_max / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
             "config": {
                 "workload": f"BASELINE {args.workload}: SEPAIHRD {pb.n} age groups, {solver_name}, "
                             f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
                 "chains_per_gpu": B, "n_params": P, "abs_err": pb.abs_err, "rel_err": pb.rel_err,
-                "arith": args.arith,
-                "other_arith": {"mode": other, "steps": n_other, "ms_per_step": other_wall_ms,
+                "arith": args.arith if args.precision == "f64" else "f32 state (fma), fp64 likelihood / time / theta",
+                "other_arith": {"mode": other if args.precision == "f64" else "f64 " + other, "steps": n_other, "ms_per_step": other_wall_ms,
                                 "ms_per_step_on_stream": other_ms,
                                 "evals_per_s_per_gpu": B / (other_wall_ms * 1e-3)},
                 "parity_mode": PARITY_NOTES,
@@ -346,8 +354,9 @@ def main():
             # HBM and not on MFMA (a 4x4 contact contraction is far below a tile); the HBM figures BASELINE.json asks
             # for follow in "hbm"
             "roofline": {
-                "bound": "fp64_valu", "achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
+                "bound": "fp64_valu" if args.precision == "f64" else "fp32_valu", "achieved": fp64_tflops,
+                "peak": FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fp64_tflops / (FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS),
                 "algorithmic_flops_per_eval": flops_eval,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": ("profile (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this "

@@ -77,6 +77,15 @@ extern "C" {
 #define SEPAIHRD_ARITH_STRICT 0 /* no FMA contraction: same operation sequence as the CPU build */
 #define SEPAIHRD_ARITH_FMA 1    /* mul+add fused where the source order allows (each a*b+c rounded once) */
 
+/* number type of the ODE state (BASELINE configs[4]: "fp32 vs fp64 tolerance sweep").  F64 is the reference's
+ * arithmetic and the only mode with a parity contract.  F32: state, stage derivatives and model coefficients in fp32;
+ * the log-likelihood (terms, log, sums), time and theta stay fp64, and the cumulative compartments the likelihood
+ * differences (D, CumH, CumICU; also R) are integrated as per-output-interval fp32 accumulators folded into fp64
+ * totals, so that a day's increment keeps full fp32 relative precision.  Accuracy vs F64 per tolerance: DESIGN.md 6.
+ * 3 to 16 age classes; no ensemble summaries in F32. */
+#define SEPAIHRD_PRECISION_F64 0
+#define SEPAIHRD_PRECISION_F32 1
+
 /* per-chain status */
 #define SEPAIHRD_STATUS_OK 0
 #define SEPAIHRD_STATUS_INVALID 1      /* calculate() returned lowest(): bad theta / S<0 / NaN total */
@@ -132,7 +141,7 @@ typedef struct sepaihrd_problem {
     int32_t constraint_mode;
     int32_t arith;
     int32_t max_attempts; /* 0 = default (1 000 000 step attempts per chain) */
-    int32_t reserved0;
+    int32_t precision;    /* SEPAIHRD_PRECISION_F64 (0, default) or _F32 */
 
     const double *times;          /* [T] */
     const double *N;              /* [n] */
@@ -166,6 +175,7 @@ int sepaihrd_abi_version(void);
  * (ModelCalibrator.cpp:64,90; MetropolisHastingsSampler.cpp:207-209). */
 int sepaihrd_set_constraint_mode(sepaihrd_ctx *ctx, int mode);
 int sepaihrd_set_arith(sepaihrd_ctx *ctx, int arith);
+int sepaihrd_set_precision(sepaihrd_ctx *ctx, int precision);
 
 /* Host-pointer form.  theta: B x P, chain-major (one Eigen::VectorXd after another).
  * Outputs (any may be NULL except loglik): loglik[B]; status[B]; n_accept[B]/n_reject[B] =

@@ -23,6 +23,7 @@ struct sepaihrd_ctx {
     int device = 0;
     int solver = 0;
     int arith = 0;
+    int precision = 0;  // SEPAIHRD_PRECISION_F64 / _F32
     DevProblem dp{};
     std::vector<void*> allocs;
     // host copies needed by sepaihrd_apply_constraints
@@ -141,6 +142,7 @@ int ensure_workspace(sepaihrd_ctx* c, size_t chains) {
 // Does a launch of B chains use the ctx-owned workspace?  Decided by the kernel translation unit (the launch code
 // takes the same branches); < 0: unsupported lanes-per-chain.
 int needs_workspace(const sepaihrd_ctx* c, int B, int force_split) {
+    if (c->precision == SEPAIHRD_PRECISION_F32 && !force_split) return c->dp.lpc >= 4 ? 0 : -4;  // likelihood inline
     return c->arith == SEPAIHRD_ARITH_FMA ? launch_needs_workspace_fma(c->dp, c->solver, B, force_split)
                                           : launch_needs_workspace_strict(c->dp, c->solver, B, force_split);
 }
@@ -247,6 +249,13 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
     ctx->device = device;
     ctx->solver = pb->solver;
     ctx->arith = pb->arith == SEPAIHRD_ARITH_FMA ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT;
+    if (pb->precision != SEPAIHRD_PRECISION_F64 && pb->precision != SEPAIHRD_PRECISION_F32) {
+        set_err(err, errlen, "unknown precision"); delete ctx; return nullptr;
+    }
+    if (pb->precision == SEPAIHRD_PRECISION_F32 && lanes_per_chain(n) < 4) {
+        set_err(err, errlen, "the fp32-state arm is built for 3 to 16 age classes"); delete ctx; return nullptr;
+    }
+    ctx->precision = pb->precision;
     ctx->n = n; ctx->T = T; ctx->P = P;
     ctx->host_N.assign(pb->N, pb->N + n);
     if (const char* mb = std::getenv("SEPAIHRD_WORKSPACE_MB")) {  // likelihood-workspace budget (default 24 GiB)
@@ -434,6 +443,16 @@ int sepaihrd_set_arith(sepaihrd_ctx* ctx, int arith) {
     return SEPAIHRD_OK;
 }
 
+int sepaihrd_set_precision(sepaihrd_ctx* ctx, int precision) {
+    if (!ctx || (precision != SEPAIHRD_PRECISION_F64 && precision != SEPAIHRD_PRECISION_F32)) return SEPAIHRD_E_INVALID_ARG;
+    if (precision == SEPAIHRD_PRECISION_F32 && ctx->dp.lpc < 4) {
+        ctx->last_error = "the fp32-state arm is built for 3 to 16 age classes";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
+    ctx->precision = precision;
+    return SEPAIHRD_OK;
+}
+
 int sepaihrd_reserve(sepaihrd_ctx* ctx, int max_B) {
     if (!ctx || max_B < 0) return SEPAIHRD_E_INVALID_ARG;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
@@ -486,8 +505,9 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
                         d_traj ? d_traj + off * traj_per_chain : nullptr,
                         ctx->ws_cum, ctx->ws_rows, ctx->ws_status, e1, 0};
         const double* th = d_theta + off * (size_t)ctx->P;
-        const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
-                                                         : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
+        const int rc = ctx->precision == SEPAIHRD_PRECISION_F32 ? launch_eval_f32(ctx->dp, ctx->solver, th, nb, out, stream)
+                       : ctx->arith == SEPAIHRD_ARITH_FMA       ? launch_eval_fma(ctx->dp, ctx->solver, th, nb, out, stream)
+                                                                : launch_eval_strict(ctx->dp, ctx->solver, th, nb, out, stream);
         if (rc != 0) {
             ctx->last_error = rc == -4 ? "unsupported lanes-per-chain"
                               : rc == -5 ? "launch needs the likelihood workspace but none was sized for it"
@@ -659,6 +679,10 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, c
         ctx->last_error = "ensemble_quantiles: a sepaihrd_eval_batch_begin is pending on this context";
         return SEPAIHRD_E_INVALID_ARG;
     }
+    if (ctx->precision != SEPAIHRD_PRECISION_F64) {
+        ctx->last_error = "ensemble_quantiles: the ensemble summaries read the fp64 integrator's parked increments (set precision F64)";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const DevProblem& dp = ctx->dp;
     const int Tp = dp.T - dp.runup_offset;
@@ -798,8 +822,9 @@ int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx* ctx, int32_t batch_chains, 
     std::memset(info, 0, sizeof(*info));
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     LaunchInfo li{};
-    const int rc = ctx->arith == SEPAIHRD_ARITH_FMA ? kernel_info_fma(ctx->dp, ctx->solver, batch_chains, &li)
-                                                     : kernel_info_strict(ctx->dp, ctx->solver, batch_chains, &li);
+    const int rc = ctx->precision == SEPAIHRD_PRECISION_F32 ? kernel_info_f32(ctx->dp, ctx->solver, &li)
+                   : ctx->arith == SEPAIHRD_ARITH_FMA       ? kernel_info_fma(ctx->dp, ctx->solver, batch_chains, &li)
+                                                            : kernel_info_strict(ctx->dp, ctx->solver, batch_chains, &li);
     if (rc != 0) { ctx->last_error = "kernel_info failed"; return SEPAIHRD_E_HIP; }
     info->lanes_per_chain = li.lanes_per_chain;
     info->chains_per_wave = WAVE / li.lanes_per_chain;

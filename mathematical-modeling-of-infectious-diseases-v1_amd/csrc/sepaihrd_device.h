@@ -89,6 +89,9 @@ int launch_eval_fma(const DevProblem& pb, int solver, const double* d_theta, int
 // Decided in the kernel translation unit, next to the launch code that takes the same branches.
 int launch_needs_workspace_strict(const DevProblem& pb, int solver, int B, int force_split);
 int launch_needs_workspace_fma(const DevProblem& pb, int solver, int B, int force_split);
+// fp32-state arm (csrc/sepaihrd_kernels_f32.hip): likelihood inline, no workspace; -4 for lanes-per-chain it is not built for
+int launch_eval_f32(const DevProblem& pb, int solver, const double* d_theta, int B, const EvalOutputs& out, void* stream);
+int kernel_info_f32(const DevProblem& pb, int solver, LaunchInfo* info);
 // batch <= 0: the large-batch kernel
 int kernel_info_strict(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
 int kernel_info_fma(const DevProblem& pb, int solver, int batch, LaunchInfo* info);

@@ -59,130 +59,7 @@
 namespace sepaihrd {
 namespace {
 
-// ----------------------------------------------------------------------------------
-// cross-lane helpers: a chain is LPC adjacent lanes
-// ----------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// row_newbcast (gfx90a+): lane LA of each 16-lane row into the lanes of banks BA, then (BB != 0) lane LB into
-// the lanes of banks BB; a bank = four adjacent lanes.  No LDS traffic and nothing to wait for, unlike
-// ds_bpermute behind __shfl (the n = 16 RHS did 32 of those per call with ~15 waits: LDS latency, not
-// arithmetic, set its pace).
-template <int LA, int BA, int LB, int BB>
-__device__ __forceinline__ double dpp_bcast_row(double v) {
-    // row_newbcast is the one DPP control the double-precision ALU accepts on 64-bit operands (gfx90a+):
-    // v_mov_b64_dpp, one instruction per value.  First move into ALL banks (no "old" value to materialise), the
-    // second overwrites banks BB only.
-    (void)BA;
-    double r = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + LA, 0xf, 0xf, true);
-    if constexpr (BB != 0) r = __builtin_amdgcn_update_dpp(r, v, 0x150 + LB, 0xf, BB, false);
-    return r;
-}
-
-// acc += m * (lane LANE of src's 16-lane row), in the lanes of banks BANKS: v_fmac_f64 with its first source through
-// DPP row_newbcast -- the broadcast costs no instruction of its own.  Inline asm is opaque to the hazard pass, so the
-// first term of a chain carries the two wait states a DPP read needs after the VALU write of `src`.
-template <int LANE, int BANKS, bool FIRST>
-__device__ __forceinline__ void fmac_row_bcast(double& acc, double src, double m) {
-    if constexpr (FIRST)
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
-            : "+v"(acc) : "v"(src), "v"(m), "n"(LANE), "n"(BANKS));
-    else
-        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
-            : "+v"(acc) : "v"(src), "v"(m), "n"(LANE), "n"(BANKS));
-}
-
-// value held by lane J of my chain group
-template <int LPC, int J>
-__device__ __forceinline__ double group_bcast(double v) {
-    if constexpr (LPC == 1) {
-        return v;
-    } else if constexpr (LPC == 2) {
-        return dpp_move<(J) | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // quad_perm
-    } else if constexpr (LPC == 4) {
-        return dpp_move<J * 0x55>(v);  // quad_perm:[J,J,J,J]
-    } else if constexpr (LPC == 16) {
-        return dpp_bcast_row<J, 0xf, J, 0x0>(v);  // row_newbcast:J -- lane J of every 16-lane row
-    } else if constexpr (LPC == 8) {
-        // two chains per 16-lane row: banks 0-1 (lanes 0-7) take lane J, banks 2-3 (lanes 8-15) take lane 8+J
-        return dpp_bcast_row<J, 0x3, 8 + J, 0xc>(v);
-    } else {
-        return __shfl(v, J, LPC);
-    }
-}
-
-// NaN-ignoring max (std::max(init, v) with init never NaN: odeint's norm_inf).  fmax = v_max_f64 returns
-// the non-NaN operand, which is exactly (m < v) ? v : m for a non-NaN m -- one instruction instead of three.
-__device__ __forceinline__ double max_keep(double m, double v) { return fmax(m, v); }
-
-template <int LPC>
-__device__ __forceinline__ double group_max(double m) {
-    if constexpr (LPC == 1) {
-        return m;
-    } else if constexpr (LPC == 2) {
-        return max_keep(m, dpp_move<0xB1>(m));  // quad_perm:[1,0,3,2]
-    } else if constexpr (LPC == 4) {
-        m = max_keep(m, dpp_move<0xB1>(m));
-        return max_keep(m, dpp_move<0x4E>(m));  // quad_perm:[2,3,0,1]
-    } else if constexpr (LPC == 8 || LPC == 16) {
-        m = max_keep(m, dpp_move<0xB1>(m));   // quad_perm:[1,0,3,2]
-        m = max_keep(m, dpp_move<0x4E>(m));   // quad_perm:[2,3,0,1]: every quad holds its max
-        m = max_keep(m, dpp_move<0x141>(m));  // row_half_mirror: lane i <-> 7 - i within each 8 lanes
-        if constexpr (LPC == 16) m = max_keep(m, dpp_move<0x140>(m));  // row_mirror: lane i <-> 15 - i
-        return m;
-    } else {
-#pragma unroll
-        for (int off = LPC / 2; off > 0; off >>= 1) m = max_keep(m, __shfl_xor(m, off));
-        return m;
-    }
-}
-
-// any() over my chain group
-template <int LPC>
-__device__ __forceinline__ bool group_any(bool pred, int lane) {
-    const unsigned long long b = __ballot(pred);
-    if constexpr (LPC == 64) {
-        return b != 0ull;
-    } else {
-        const unsigned long long mask = ((1ull << LPC) - 1ull) << (lane & ~(LPC - 1));
-        return (b & mask) != 0ull;
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// tableaus, written as Boost.Odeint writes them: quotients of doubles; the Dopri5 error
-// weights are DIFFERENCES of rounded quotients (runge_kutta_dopri5.hpp do_step_impl).
-// ----------------------------------------------------------------------------------
-namespace dp {
-constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
-constexpr double b21 = 1.0 / 5;
-constexpr double b31 = 3.0 / 40, b32 = 9.0 / 40;
-constexpr double b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9;
-constexpr double b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729;
-constexpr double b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176,
-                 b65 = -5103.0 / 18656;
-constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
-constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695, dc4 = c4 - 393.0 / 640,
-                 dc5 = c5 - (-92097.0 / 339200), dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
-}  // namespace dp
-namespace ck {
-constexpr double c2 = 1.0 / 5, c3 = 3.0 / 10, c4 = 3.0 / 5, c5 = 1.0, c6 = 7.0 / 8;
-constexpr double a21 = 1.0 / 5;
-constexpr double a31 = 3.0 / 40, a32 = 9.0 / 40;
-constexpr double a41 = 3.0 / 10, a42 = -9.0 / 10, a43 = 6.0 / 5;
-constexpr double a51 = -11.0 / 54, a52 = 5.0 / 2, a53 = -70.0 / 27, a54 = 35.0 / 27;
-constexpr double a61 = 1631.0 / 55296, a62 = 175.0 / 512, a63 = 575.0 / 13824, a64 = 44275.0 / 110592,
-                 a65 = 253.0 / 4096;
-constexpr double b1 = 37.0 / 378, b3 = 250.0 / 621, b4 = 125.0 / 594, b6 = 512.0 / 1771;
-constexpr double db1 = 37.0 / 378 - 2825.0 / 27648, db3 = 250.0 / 621 - 18575.0 / 48384,
-                 db4 = 125.0 / 594 - 13525.0 / 55296, db5 = -277.0 / 14336, db6 = 512.0 / 1771 - 1.0 / 4;
-}  // namespace ck
+#include "sepaihrd_dev_common.inc"  // cross-lane helpers, tableaus, constraints, schedule lookup, log_pos
 
 // ----------------------------------------------------------------------------------
 // per-lane model record
@@ -301,48 +178,6 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
 #endif
 }
 
-// SEPAIHRDParameterManager.cpp:302-313 / :326-343
-__device__ __forceinline__ double reflect_bound(double value, double minb, double maxb) {
-    if (minb >= maxb) return minb;
-    const double width = maxb - minb;
-    double y = fmod(value - minb, 2.0 * width);
-    if (y < 0) y += 2.0 * width;
-    if (y <= width) return minb + y;
-    return maxb - (y - width);
-}
-__device__ __forceinline__ double constrain(double v, double lo, double hi, int has_bounds, int mode) {
-    if (has_bounds) {
-        if (lo > hi) { const double t = lo; lo = hi; hi = t; }
-        if (mode == 0) {
-            const double m = (v < lo) ? lo : v;  // std::max(v, lo)
-            return (hi < m) ? hi : m;            // std::min(m, hi)
-        }
-        return reflect_bound(v, lo, hi);
-    }
-    if (mode == 0) return (0.0 < v) ? v : 0.0;  // std::max(0.0, v)
-    return fabs(v);
-}
-
-// Merged beta*kappa schedule of one chain.  Segment j = (mends[j-1], mends[j]], value index = #(mends < t).
-struct Schedule {
-    const double* me;   // LDS: merged end times, +inf padded to an even count (block-uniform)
-    const double* bkv;  // LDS: this chain's beta*kappa per merged segment [nm + 1]
-    double lo, hi, bk;  // cached segment (lo, hi] and its value
-};
-
-// segment indices of two times in one pass over the merged end times (uniform LDS broadcast reads)
-__device__ __forceinline__ void segment_index2(const Schedule& s, int nm_pad, double ta, double tb, int& ca,
-                                               int& cb) {
-    ca = 0; cb = 0;
-    for (int j = 0; j < nm_pad; j += 2) {
-        const double2 e = *reinterpret_cast<const double2*>(s.me + j);
-        ca += (ta > e.x) ? 1 : 0; ca += (ta > e.y) ? 1 : 0;
-        cb += (tb > e.x) ? 1 : 0; cb += (tb > e.y) ? 1 : 0;
-    }
-}
-
-#define SEP_UNROLL _Pragma("unroll")
-
 // Diagnostic build only (-DSEPAIHRD_STAMPS): s_memtime stamps at section boundaries of the RK loop,
 // summed per wave and written to out.ll_parts of the wave's first chain.  Never in the product build.
 #ifdef SEPAIHRD_STAMPS
@@ -355,47 +190,6 @@ __device__ __forceinline__ void segment_index2(const Schedule& s, int nm_pad, do
 #else
 #define SEP_STAMP(var) do { } while (0)
 #endif
-
-// ----------------------------------------------------------------------------------
-// natural log for the Poisson term.  Argument reduction x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt(2),
-// s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the classic degree-14 minimax R
-// (error < 2^-58.45 on the reduced interval); < 1 ulp overall in ~45 instructions, no branches, so
-// the three logs of one output day interleave instead of serialising three dependent chains.
-// Explicit fma() here is not contraction: the likelihood's log is a libm call in the reference
-// (std::log), never bit-pinned.  Domain: x >= 1e-10 by construction (sim + epsilon); +inf and NaN
-// pass through, which is all that can reach it from a blown-up state.
-// ----------------------------------------------------------------------------------
-__device__ __forceinline__ double log_pos(double x) {
-    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                     Lg7 = 1.479819860511658591e-01;
-    int k = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^k, m in [0.5, 1)
-    double m = __builtin_amdgcn_frexp_mant(x);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m + m : m;                            // [sqrt(1/2), sqrt(2))
-    k = low ? k - 1 : k;
-    const double f = m - 1.0;
-    const double dk = (double)k;
-    // s = f / (2 + f): denominator in [1.70, 2.42], so a Newton-refined reciprocal and one residual
-    // correction give the correctly rounded quotient's neighbourhood (<= 1 ulp) without the IEEE
-    // division's scaling / fix-up instructions
-    const double den = 2.0 + f;
-    double r = __builtin_amdgcn_rcp(den);
-    r = fma(fma(-den, r, 1.0), r, r);
-    r = fma(fma(-den, r, 1.0), r, r);
-    double sdiv = f * r;
-    sdiv = fma(fma(-den, sdiv, f), r, sdiv);
-    const double z = sdiv * sdiv;
-    const double w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double res = dk * ln2_hi - ((hfsq - fma(sdiv, hfsq + R, dk * ln2_lo)) - f);
-    return (x < INFINITY) ? res : x;                // +inf -> +inf, NaN -> NaN
-}
 
 // |e| / s of the error norm.  strict: the IEEE division of the CPU build.  fma: Newton-refined
 // reciprocal (4 instructions instead of 15); s > 0 is a tolerance scale, far from the overflow /

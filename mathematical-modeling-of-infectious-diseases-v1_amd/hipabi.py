@@ -30,7 +30,7 @@ class sepaihrd_problem(C.Structure):
         ("abi_version", C.c_int32), ("n_age", C.c_int32), ("n_times", C.c_int32), ("n_obs", C.c_int32),
         ("n_beta", C.c_int32), ("n_kappa", C.c_int32), ("n_params", C.c_int32), ("solver", C.c_int32),
         ("constraint_mode", C.c_int32), ("arith", C.c_int32), ("max_attempts", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("precision", C.c_int32),
         ("times", _dp), ("N", _dp), ("M", _dp),
         ("a", _dp), ("h_infec", _dp), ("p", _dp), ("h", _dp), ("icu", _dp), ("d_H", _dp), ("d_ICU", _dp),
         ("d_community", _dp),
@@ -56,7 +56,7 @@ class sepaihrd_kernel_info(C.Structure):
 # every symbol include/sepaihrd_hip.h declares
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
-    "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_eval_batch",
+    "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_set_precision", "sepaihrd_eval_batch",
     "sepaihrd_eval_batch_device", "sepaihrd_eval_batch_begin", "sepaihrd_eval_batch_end", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
     "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
@@ -98,6 +98,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_abi_version.restype = C.c_int
     lib.sepaihrd_set_constraint_mode.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_arith.argtypes = [vp, C.c_int]
+    lib.sepaihrd_set_precision.argtypes = [vp, C.c_int]
     lib.sepaihrd_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_eval_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
@@ -139,6 +140,7 @@ def build_problem_struct(pb: SEPAIHRDProblem, keep: list) -> sepaihrd_problem:
     s.n_beta, s.n_kappa, s.n_params = len(pb.beta_values), len(pb.kappa_values), pb.n_params
     s.solver, s.constraint_mode, s.arith = pb.solver, pb.constraint_mode, pb.arith
     s.max_attempts = int(getattr(pb, "max_attempts", 0))
+    s.precision = int(getattr(pb, "precision", 0))
 
     def dbl(x):
         a = np.ascontiguousarray(x, dtype=np.float64)
@@ -204,6 +206,10 @@ class HipObjective:
 
     def set_arith(self, arith: int):
         self._check(self.lib.sepaihrd_set_arith(self.ctx, arith), "set_arith")
+
+    def set_precision(self, precision: int):
+        """PRECISION_F64 (reference arithmetic) or PRECISION_F32 (fp32 state, fp64 likelihood: BASELINE configs[4])."""
+        self._check(self.lib.sepaihrd_set_precision(self.ctx, int(precision)), "set_precision")
 
     def calculate(self, theta) -> float:
         return float(self.eval_batch(np.asarray(theta, dtype=np.float64)[None, :])["loglik"][0])

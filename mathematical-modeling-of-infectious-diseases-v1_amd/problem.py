@@ -23,6 +23,7 @@ NUM_COMPARTMENTS = 11
 SOLVER_DOPRI5, SOLVER_CASH_KARP54 = 0, 1
 CONSTRAINT_CLAMP, CONSTRAINT_REFLECT = 0, 1
 ARITH_STRICT, ARITH_FMA = 0, 1
+PRECISION_F64, PRECISION_F32 = 0, 1  # number type of the ODE state (include/sepaihrd_hip.h)
 
 # enum sepaihrd_field (include/sepaihrd_hip.h)
 F_NONE = -1
@@ -123,6 +124,7 @@ class SEPAIHRDProblem:
     rel_err: float = 1e-6
     dt_hint: float = 1.0
     arith: int = ARITH_STRICT
+    precision: int = PRECISION_F64
     max_attempts: int = 0  # build-side guard on RK step attempts per chain, 0 = default (1e6)
     # calibrated starting point (getCurrentParameters of the shipped model)
     base_theta: Optional[np.ndarray] = None

@@ -472,3 +472,66 @@ def test_forced_small_batch_form_sizes_its_own_workspace():
             assert r.returncode == 0, r.stdout + r.stderr
             res[mode] = np.load(path)
         assert np.array_equal(res["1"], res["unset"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp32-state arm of BASELINE configs[4] (csrc/sepaihrd_kernels_f32.hip).  No bit contract: the reference has no fp32
+# path.  Its test is the distance from the fp64 kernel at the same tolerance, with the bars set from what a 24-bit
+# coefficient can carry: a growth rate off by ~5e-8 per day is ~1e-4 relative after a thousand days.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("solver", [0, 1])
+def test_fp32_arm_on_config5_workload(mm, c5_problem, solver):
+    from mmid_amd import draws as dr
+    pb = c5_problem.with_(abs_err=1e-4, rel_err=1e-4, solver=solver, arith=mm.ARITH_FMA)
+    theta = dr.jitter_draws(pb, 1, 70)
+    f64 = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    f32 = mm.HipObjective(pb.with_(precision=mm.PRECISION_F32)).eval_batch(theta, want_traj=True)
+    assert np.array_equal(f32["status"], f64["status"]) and np.all(f64["status"] == 0)
+    # same controller on nearly the same error estimates: the step counts differ by a handful at most
+    assert np.all(np.abs((f32["n_accept"] + f32["n_reject"]) - (f64["n_accept"] + f64["n_reject"])) <= 0.01 * f64["n_accept"])
+    err = rel_state_err(f32["traj"], f64["traj"], pb)
+    assert err.max() < 5e-4, err.max()                      # measured 8e-5
+    assert np.median(err.max(axis=(1, 2))) < 2e-4
+    # likelihood: fp64 terms and sums over fp32 increments; measured max |diff| 17 on values of ~1.5e4
+    assert np.max(np.abs(f32["loglik"] - f64["loglik"]) / np.abs(f64["loglik"])) < 5e-3
+    np.testing.assert_allclose(f32["ll_parts"].sum(axis=1), f32["loglik"], rtol=1e-12)
+    # the cumulative compartments come out of the fp64 totals: monotone, and their daily increments are what the
+    # likelihood saw (no 24-bit staircase on a compartment of 1e5 people)
+    n = pb.n
+    cum = f32["traj"][:, :, 9 * n:10 * n]
+    assert np.all(np.diff(cum, axis=1) >= 0)
+    inc32, inc64 = np.diff(cum, axis=1), np.diff(f64["traj"][:, :, 9 * n:10 * n], axis=1)
+    big = inc64 > 1.0
+    assert np.max(np.abs(inc32[big] - inc64[big]) / inc64[big]) < 1e-3
+    # a likelihood-only launch gives the same numbers as the trajectory launch
+    again = mm.HipObjective(pb.with_(precision=mm.PRECISION_F32)).eval_batch(theta)
+    assert np.array_equal(again["loglik"], f32["loglik"])
+
+
+@pytest.mark.parametrize("n_age", [3, 4, 8])
+def test_fp32_arm_other_lane_layouts(mm, shipped, n_age):
+    """4 lanes per chain (n = 3 pads one, n = 4) and 8 lanes per chain (two chains per DPP row) on the shipped
+    326-point problem at its own tolerance 1e-6, ragged batch."""
+    from mmid_amd import draws as dr
+    pb = mm.restrict_age_classes(shipped, [0, 1, 2]) if n_age == 3 else (shipped if n_age == 4 else mm.widen_age_classes(shipped, 2))
+    pb = pb.with_(arith=mm.ARITH_FMA)
+    theta = dr.jitter_draws(pb, 3, 37)
+    f64 = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    f32 = mm.HipObjective(pb.with_(precision=mm.PRECISION_F32)).eval_batch(theta, want_traj=True)
+    assert np.array_equal(f32["status"], f64["status"]) and np.all(f64["status"] == 0)
+    assert rel_state_err(f32["traj"], f64["traj"], pb).max() < 5e-4
+    assert np.max(np.abs(f32["loglik"] - f64["loglik"]) / np.abs(f64["loglik"])) < 2e-3
+
+
+def test_fp32_arm_limits_are_errors_not_fallbacks(mm, shipped):
+    two = mm.restrict_age_classes(shipped, [0, 1])
+    with pytest.raises(RuntimeError, match="fp32"):
+        mm.HipObjective(two.with_(precision=mm.PRECISION_F32))
+    hip = mm.HipObjective(shipped.with_(precision=mm.PRECISION_F32))
+    hip.set_initial_state_mode(1)
+    with pytest.raises(RuntimeError, match="F64"):
+        hip.ensemble_quantiles(np.asarray(shipped.base_theta)[None, :], [0.5])
+    hip.set_precision(mm.PRECISION_F64)                       # the same context switches back
+    hip.set_initial_state_mode(0)
+    ref = mm.HipObjective(shipped).eval_batch(np.asarray(shipped.base_theta)[None, :])
+    assert np.array_equal(hip.eval_batch(np.asarray(shipped.base_theta)[None, :])["loglik"], ref["loglik"])

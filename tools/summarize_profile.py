@@ -18,8 +18,10 @@ arith_flag = "1" if (bench or {}).get("config", {}).get("arith", "fma") == "fma"
 import re
 # ... or, for tolerance-mode batches of up to 4096 chains of a 4-age problem, the 16-lane form (fma only)
 pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + "," + r"|sepaihrd_eval_quad_kernel<\d+, " + arith_flag + ">")
+if (bench or {}).get("dtype") == "f32":
+    pat = re.compile(r"sepaihrd_eval_f32_kernel<")
 counters = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64", "pmc_f32"):
     files = sorted(glob.glob(f"{src}/{d}/*/*counter_collection.csv"), key=os.path.getmtime)
     for f in files[-1:]:  # newest run only: gpurun merges into an existing directory
         acc = collections.defaultdict(list)
