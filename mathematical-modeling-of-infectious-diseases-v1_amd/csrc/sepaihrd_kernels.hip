@@ -935,12 +935,13 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
 // Does a launch of B chains park the daily increments in the ctx-owned workspace (cum / rows / wstatus)?  The ONE
 // place that decides it: launch_one below takes the same branches, and the C ABI sizes the workspace from this.
 template <int LPC, int SOLVER>
-int needs_workspace_one(const DevProblem&, int B, int force_split) {
+int needs_workspace_one(const DevProblem& pb, int B, int force_split) {
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
     if constexpr (LPC == 4) {
-        if (lane_split_wanted(B)) return 1;
+        // the 16-lane form evaluates the likelihood on consumer waves of the same workgroup: no workspace
+        if (lane_split_wanted(B)) return (quad_fused_wanted() && !force_split && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS) ? 0 : 1;
     }
     return (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || force_split) ? 1 : 0;
 }
@@ -954,7 +955,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
         if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
-    if (needs_workspace_one<LPC, SOLVER>(pb, B, out.force_split))
+    if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
         // two waves per SIMD only pay when there are two waves for every SIMD
@@ -964,7 +965,8 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
 }
 
 template <typename K>
-int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const char* name) {
+int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const char* name, int block_threads = WAVE,
+            size_t lds_bytes = 0) {
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) return -3;
     info->vgprs = attr.numRegs;
@@ -972,7 +974,7 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
     info->lds_static = (int)attr.sharedSizeBytes;
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, WAVE, eval_lds_bytes(pb)) != hipSuccess) nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds_bytes ? lds_bytes : eval_lds_bytes(pb)) != hipSuccess) nb = -1;
     info->max_blocks_per_cu = nb;
     info->lanes_per_chain = lanes;
     info->name = name;
@@ -983,7 +985,8 @@ template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(batch))
-            return info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
+            return quad_fused_wanted() ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", 8 * WAVE, quad_fused_lds_bytes(pb))
+                                       : info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name);
 }

@@ -43,9 +43,20 @@ def test_end_to_end_calibration_driver(tmp_path):
     assert summary["ensemble_valid"] == summary["ensemble_samples"] > 0
     rows = list(csv.reader(open(out / "posterior_trace_chain0.csv")))
     assert rows[0][:2] == ["iter", "log_posterior"] and len(rows[0]) == 2 + 62 and len(rows) == 1 + 50
-    rt = list(csv.reader(open(out / "Rt_aggregated_with_uncertainty.csv")))
-    assert len(rt) == 1 + 326 and float(rt[1][3]) > 1.0 > float(rt[-1][3]) * 0.5
-    assert len(list(csv.reader(open(out / "essential_metrics.csv")))) == 1 + summary["ensemble_samples"]
+    # post-calibration tree in the reference's layout (AnalysisWriter.cpp; what scripts/model/PostCalibrationAnalysis.py loads)
+    rt = list(csv.reader(open(out / "rt_trajectories" / "Rt_aggregated_with_uncertainty.csv")))
+    assert rt[0] == ["time", "median", "q025", "q975", "q05", "q95"]
+    assert len(rt) == 1 + 326 and float(rt[1][1]) > 1.0 > float(rt[-1][1]) * 0.5
+    assert len(list(csv.reader(open(out / "mcmc_batches" / "batch_0.csv")))) == 1 + summary["ensemble_samples"]
+    with open(os.path.join(ROOT, "tests", "golden", "reference_output_headers.json")) as fh:
+        want = json.load(fh)["files"]
+    for rel, header in want.items():
+        if rel.startswith("parameter_posteriors/posterior_samples"):
+            continue  # the fixture's two-parameter header; this run has the 62 shipped names
+        with open(out / rel) as fh:
+            assert fh.readline().rstrip("\n").split(",") == header, rel
+    med = list(csv.reader(open(out / "posterior_predictive" / "daily_hospitalizations_median.csv")))
+    assert len(med) == 1 + 306 and med[1][0] == "0"
 
 
 C_SMOKE = os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke")
