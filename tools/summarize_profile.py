@@ -17,7 +17,7 @@ except FileNotFoundError:
 arith_flag = "1" if (bench or {}).get("config", {}).get("arith", "fma") == "fma" else "0"
 import re
 # ... or, for tolerance-mode batches of up to 4096 chains of a 4-age problem, the 16-lane form (fma only)
-pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + "," + r"|sepaihrd_eval_quad_kernel<\d+, " + arith_flag + ">")
+pat = re.compile(r"sepaihrd_eval_kernel<\d+, \d+, " + arith_flag + "," + r"|sepaihrd_eval_quad_kernel<\d+, " + arith_flag + "[,>]")
 if (bench or {}).get("dtype") == "f32":
     pat = re.compile(r"sepaihrd_eval_f32_kernel<")
 counters = {}
