@@ -155,19 +155,45 @@ def cpu_baseline(pb, theta, budget_s):
 def sampler_pipeline(mm, pb, theta, iterations=None):
     """Informational, outside the timed region: the whole Adaptive-Metropolis iteration around the kernel
     (host random streams + accept test, device-resident proposal / adaptation state, one evaluation per
-    chain and iteration), proposals per second for the step's chains.  None if the host library is absent."""
+    chain and iteration), proposals per second for the step's chains.  Two runs of different length separate the
+    steady-state iteration (the slope) from the set-up and read-back of a run (history allocation, covariance
+    read-back).  None if the host library is absent."""
     try:
         iters = int(iterations or 120)
         host = mm.HostObjective(pb)
         host.metropolis_hastings(theta[:16], 1, 4, 1, device_state=True)
-        t0 = time.perf_counter()
-        r = host.metropolis_hastings(theta, 1, iters, iters // 3, adaptation_period=max(10, iters // 4), thinning=iters,
-                                     device_state=True)
-        dt = time.perf_counter() - t0
-        return {"proposals_per_s": theta.shape[0] * (iters - 1) / dt, "ms_per_iteration": dt / (iters - 1) * 1e3,
+
+        def slope(run):
+            short = max(20, iters // 3)
+            dt_s, _ = run(short)
+            dt, r = run(iters)
+            steady = (dt - dt_s) / (iters - short)
+            return steady, dt, r, short
+
+        def run_one(n):
+            t0 = time.perf_counter()
+            r = host.metropolis_hastings(theta, 1, n, n // 3, adaptation_period=max(10, n // 4), thinning=n, device_state=True)
+            return time.perf_counter() - t0, r
+        # two groups of chains, each with its own context, stream and host thread: while one group's evaluation runs
+        # the other group's accept test and draws are made (same chains, same results: chain c draws from mt19937(1 + c))
+        pair = [mm.HostObjective(pb), mm.HostObjective(pb)]
+        mm.hostabi.metropolis_hastings_groups(pair, theta[:32], 1, 4, 1)
+
+        def run_two(n):
+            t0 = time.perf_counter()
+            r = mm.hostabi.metropolis_hastings_groups(pair, theta, 1, n, n // 3, adaptation_period=max(10, n // 4), thinning=n)
+            return time.perf_counter() - t0, r
+        s1, dt1, r1, short = slope(run_one)
+        s2, dt2, r2, _ = slope(run_two)
+        same = bool(np.array_equal(r1["accept_trace"], r2["accept_trace"]))
+        steady, dt, r, groups = (s2, dt2, r2, 2) if s2 < s1 else (s1, dt1, r1, 1)
+        return {"proposals_per_s": theta.shape[0] / steady, "ms_per_iteration": steady * 1e3, "chain_groups": groups,
+                "ms_per_iteration_by_groups": {"1": s1 * 1e3, "2": s2 * 1e3}, "groups_give_identical_accept_traces": same,
+                "ms_per_iteration_incl_setup": dt / (iters - 1) * 1e3, "setup_and_readback_ms": max(0.0, (dt - steady * (iters - 1)) * 1e3),
                 "chains": int(theta.shape[0]), "iterations": iters,
                 "acceptance": float(r["accepted"].mean() / (iters - 1)),
-                "note": "includes setup and read-back of the run; sampler state resident in HBM (DESIGN.md 6c)"}
+                "note": "ms_per_iteration = slope between a %d- and a %d-iteration run (steady state), the better of one and two "
+                        "chain groups; sampler state resident in HBM, host keeps the mt19937 streams (DESIGN.md 6c)" % (short, iters)}
     except Exception as e:  # informational only
         return {"error": str(e)[:200]}
 

@@ -297,10 +297,31 @@ void sepaihrd_mh_destroy(sepaihrd_mh *mh);
 int sepaihrd_mh_evaluate_current(sepaihrd_mh *mh, double *loglik, int32_t *status);
 int sepaihrd_mh_propose(sepaihrd_mh *mh, const double *z, const double *scale, double *loglik, int32_t *status);
 int sepaihrd_mh_fetch(sepaihrd_mh *mh, double *loglik, int32_t *status);
+/* The iteration as ONE call, for callers that prepare the next proposal while the device evaluates this one:
+ *   stage_normals  z [C][P] host: the NEXT proposal's normals, copied to a second device buffer on a copy stream
+ *                  (call it while an evaluation is in flight; double-buffered, one staging per step)
+ *   step           accept [C] of the iteration just decided (NULL before the first proposal: nothing to commit),
+ *                  scale [C], and n_patch rows of the staged normals to replace (chains whose accept test took the
+ *                  branch the staged draw did not assume: patch_chain [n] lists them, patch_z is a full [C][P] array of
+ *                  which only the listed chains' rows are read); one packed upload, then
+ *                  commit -> adapt (0 none, 1 rank-one update with gamma, 2 + Cholesky refresh, 3 + full two-pass
+ *                  recompute before it) -> propose from the staged normals -> evaluation launch.  Returns at once;
+ *                  collect the values with sepaihrd_mh_fetch. */
+int sepaihrd_mh_stage_normals(sepaihrd_mh *mh, const double *z);
+/* page-locked [C][P] host buffer of the sampler to draw the next normals into (two alternate: staging from it is an
+ * asynchronous DMA, and the buffer returned after a staging is the other one) */
+double *sepaihrd_mh_staging_buffer(sepaihrd_mh *mh);
+int sepaihrd_mh_step(sepaihrd_mh *mh, const uint8_t *accept, const double *scale, const int32_t *patch_chain,
+                     const double *patch_z, int n_patch, double gamma, int adapt);
 int sepaihrd_mh_commit(sepaihrd_mh *mh, const uint8_t *accept);
 int sepaihrd_mh_adapt(sepaihrd_mh *mh, double gamma, int refresh, int recompute_full);
 int sepaihrd_mh_read_history(sepaihrd_mh *mh, const int32_t *rows, int n_rows, double *out);
 int sepaihrd_mh_read_covariance(sepaihrd_mh *mh, double *cov);
+/* commit / step read the accept byte as bit 0 = accepted, bit 1 = "this proposal is the chain's best state so far"
+ * (the caller's bookkeeping): the best states are kept on the device, [C][P], initially x0 */
+int sepaihrd_mh_read_best(sepaihrd_mh *mh, double *best);
+/* 1 while launches of this sampler are still running (hipStreamQuery, no wait): lets the caller use the time */
+int sepaihrd_mh_busy(sepaihrd_mh *mh);
 /* the constrained proposals of the last propose call, [C][P] (callers that track the best state) */
 int sepaihrd_mh_read_proposal(sepaihrd_mh *mh, double *prop);
 int sepaihrd_mh_history_length(const sepaihrd_mh *mh);

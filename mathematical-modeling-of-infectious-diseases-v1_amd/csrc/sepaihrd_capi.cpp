@@ -859,10 +859,69 @@ struct sepaihrd_mh {
     int32_t* d_rows = nullptr;
     double* d_gather = nullptr;
     size_t gather_cap = 0;
+    // sepaihrd_mh_stage_normals / sepaihrd_mh_step: a second normals buffer filled by a copy stream while the
+    // evaluation runs, and ONE packed upload per iteration (accept flags, scales, re-drawn rows) from pinned memory
+    double* d_z_stage = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_staged = nullptr;
+    bool staged = false;
+    double* h_stage[2] = {nullptr, nullptr};  // pinned [C][P] each: the caller fills one while the other's copy may still run
+    int stage_turn = 0;
+    uint8_t* h_pack = nullptr;   // pinned
+    uint8_t* d_pack = nullptr;
+    size_t pack_bytes = 0, off_scale = 0, off_chain = 0, off_rows = 0;
+    // rank-one covariance updates not yet applied (see mh_rank1_catchup_cov_kernel): consecutive history rows from
+    // pending_row0, one gamma each
+    std::vector<double> pending_gamma;
+    int pending_row0 = 0;
+    double* d_gammas = nullptr;
+    size_t gammas_cap = 0;
     std::vector<void*> allocs;
 };
 
 namespace {
+// queue the rank-one update that precedes the next proposal (history row rows - 1 with this gamma)
+void mh_queue_rank1(sepaihrd_mh* mh, double gamma) {
+    if (mh->pending_gamma.empty()) mh->pending_row0 = mh->rows - 1;
+    mh->pending_gamma.push_back(gamma);
+}
+// apply the queued updates in order (someone is about to read the covariance)
+int mh_flush_rank1(sepaihrd_mh* mh) {
+    const size_t n = mh->pending_gamma.size();
+    if (n == 0) return 0;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (n > mh->gammas_cap) {
+        if (mh->d_gammas) (void)hipFree(mh->d_gammas);
+        mh->d_gammas = nullptr;
+        mh->gammas_cap = 0;
+        if (hipMalloc((void**)&mh->d_gammas, std::max<size_t>(n, 256) * sizeof(double)) != hipSuccess) return -3;
+        mh->gammas_cap = std::max<size_t>(n, 256);
+    }
+    // pageable source: the copy is complete for the host when the call returns, the vector can be cleared
+    if (hipMemcpyAsync(mh->d_gammas, mh->pending_gamma.data(), n * sizeof(double), hipMemcpyHostToDevice, mh->stream) != hipSuccess) return -3;
+    if (hipStreamSynchronize(mh->stream) != hipSuccess) return -3;
+    const int rc = sampler_rank1_catchup(mh->st, mh->d_gammas, mh->pending_row0, (int)n, mh->stream);
+    mh->pending_gamma.clear();
+    (void)ctx;
+    return rc;
+}
+// the adaptation step before a proposal: 0 none, 1 rank-one update, 2 + Cholesky refresh of cov + eps I, 3 + full
+// two-pass recompute first (which overwrites covariance and mean: queued rank-one updates are dropped unapplied)
+int mh_adapt_step(sepaihrd_mh* mh, double gamma, int adapt) {
+    int rc = 0;
+    if (adapt >= 1) mh_queue_rank1(mh, gamma);
+    if (adapt == 2) {
+        rc = mh_flush_rank1(mh);
+        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);  // :295-300
+    } else if (adapt == 3) {
+        mh->pending_gamma.clear();
+        rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
+        if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, mh->stream);              // :190-197, kept on success
+        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);
+    }
+    return rc;
+}
+
 int mh_eval(sepaihrd_mh* mh, const double* d_theta, double* loglik, int32_t* status) {
     sepaihrd_ctx* ctx = mh->ctx;
     const int C = mh->st.C;
@@ -917,19 +976,35 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     dalloc((void**)&st.cov, CPP * sizeof(double));
     dalloc((void**)&st.chol, CPP * sizeof(double));
     dalloc((void**)&st.mean, CP * sizeof(double));
+    dalloc((void**)&st.best, CP * sizeof(double));
     dalloc((void**)&st.hist, CP * (size_t)capacity * sizeof(double));
     dalloc((void**)&mh->d_z, CP * sizeof(double));
     dalloc((void**)&mh->d_scale, (size_t)C * sizeof(double));
     dalloc((void**)&mh->d_loglik, (size_t)C * sizeof(double));
     dalloc((void**)&mh->d_status, (size_t)C * sizeof(int32_t));
     dalloc((void**)&mh->d_accept, (size_t)C);
+    dalloc((void**)&mh->d_z_stage, CP * sizeof(double));
+    {
+        auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+        mh->off_scale = up8((size_t)C);
+        mh->off_chain = mh->off_scale + (size_t)C * sizeof(double);
+        mh->off_rows = up8(mh->off_chain + (size_t)C * sizeof(int32_t));
+        mh->pack_bytes = mh->off_rows + CP * sizeof(double);
+        dalloc((void**)&mh->d_pack, mh->pack_bytes);
+        if (ok && hipHostMalloc((void**)&mh->h_pack, mh->pack_bytes, hipHostMallocDefault) != hipSuccess) { mh->h_pack = nullptr; ok = false; }
+        for (int b = 0; b < 2; ++b)
+            if (ok && hipHostMalloc((void**)&mh->h_stage[b], CP * sizeof(double), hipHostMallocDefault) != hipSuccess) { mh->h_stage[b] = nullptr; ok = false; }
+    }
     if (ok && sepaihrd_reserve(ctx, C) != SEPAIHRD_OK) ok = false;
     if (ok && hipStreamCreateWithFlags(&mh->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+    if (ok && hipStreamCreateWithFlags(&mh->copy_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+    if (ok && hipEventCreateWithFlags(&mh->ev_staged, hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok) {
         std::vector<double> cov_all(CPP);
         for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
         ok = hipMemcpy(st.x, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(st.mean, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(st.best, x0, CP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(st.cov, cov_all.data(), CPP * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemsetAsync(st.chol, 0, CPP * sizeof(double), mh->stream) == hipSuccess;
     }
@@ -938,6 +1013,10 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     if (!ok) {
         ctx->last_error = "mh_create: device allocation or initialisation failed (history = C * capacity * P doubles)";
         for (void* p : mh->allocs) (void)hipFree(p);
+        if (mh->h_pack) (void)hipHostFree(mh->h_pack);
+        for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
+        if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
+        if (mh->copy_stream) (void)hipStreamDestroy(mh->copy_stream);
         if (mh->stream) (void)hipStreamDestroy(mh->stream);
         delete mh;
         return nullptr;
@@ -949,10 +1028,15 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
 void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (!mh) return;
     (void)hipSetDevice(mh->ctx->device);
+    if (mh->copy_stream) { (void)hipStreamSynchronize(mh->copy_stream); (void)hipStreamDestroy(mh->copy_stream); }
     if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
+    if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
+    if (mh->h_pack) (void)hipHostFree(mh->h_pack);
+    for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
     for (void* p : mh->allocs) (void)hipFree(p);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
     if (mh->d_gather) (void)hipFree(mh->d_gather);
+    if (mh->d_gammas) (void)hipFree(mh->d_gammas);
     delete mh;
 }
 
@@ -980,6 +1064,61 @@ int sepaihrd_mh_propose(sepaihrd_mh* mh, const double* z, const double* scale, d
         return sepaihrd_eval_batch_device(ctx, mh->st.prop, mh->st.C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr,
                                           mh->stream);
     return mh_eval(mh, mh->st.prop, loglik, status);
+}
+
+double* sepaihrd_mh_staging_buffer(sepaihrd_mh* mh) { return mh ? mh->h_stage[mh->stage_turn] : nullptr; }
+
+int sepaihrd_mh_stage_normals(sepaihrd_mh* mh, const double* z) {
+    if (!mh || !z) return SEPAIHRD_E_INVALID_ARG;
+    if (z == mh->h_stage[mh->stage_turn]) mh->stage_turn ^= 1;  // page-locked source: a real DMA; the next fill goes to the other buffer
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const size_t CP = (size_t)mh->st.C * mh->st.P;
+    HIP_TRY(hipMemcpyAsync(mh->d_z_stage, z, CP * sizeof(double), hipMemcpyHostToDevice, mh->copy_stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipEventRecord(mh->ev_staged, mh->copy_stream), ctx, return SEPAIHRD_E_HIP);
+    mh->staged = true;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_step(sepaihrd_mh* mh, const uint8_t* accept, const double* scale, const int32_t* patch_chain, const double* patch_z,
+                     int n_patch, double gamma, int adapt) {
+    if (!mh || !scale || n_patch < 0 || (n_patch > 0 && (!patch_chain || !patch_z)) || adapt < 0 || adapt > 3) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    const int C = mh->st.C, P = mh->st.P;
+    if (!mh->staged) { ctx->last_error = "mh_step: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
+    if (n_patch > C) { ctx->last_error = "mh_step: more patched rows than chains"; return SEPAIHRD_E_INVALID_ARG; }
+    for (int k = 0; k < n_patch; ++k)
+        if (patch_chain[k] < 0 || patch_chain[k] >= C) { ctx->last_error = "mh_step: patched chain out of range"; return SEPAIHRD_E_INVALID_ARG; }
+    if (accept && mh->rows >= mh->st.capacity) { ctx->last_error = "mh_step: history capacity exhausted"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    hipStream_t st = mh->stream;
+    // one upload: [accept C | scale C | chains n | rows n x P]
+    if (accept) std::memcpy(mh->h_pack, accept, (size_t)C);
+    std::memcpy(mh->h_pack + mh->off_scale, scale, (size_t)C * sizeof(double));
+    if (n_patch > 0) {
+        std::memcpy(mh->h_pack + mh->off_chain, patch_chain, (size_t)n_patch * sizeof(int32_t));
+        // patch_z is a full [C][P] array of which the listed chains' rows are valid: gathered straight into the upload
+        double* dst = reinterpret_cast<double*>(mh->h_pack + mh->off_rows);
+        for (int k = 0; k < n_patch; ++k)
+            std::memcpy(dst + (size_t)k * P, patch_z + (size_t)patch_chain[k] * P, (size_t)P * sizeof(double));
+    }
+    const size_t used = n_patch > 0 ? mh->off_rows + (size_t)n_patch * P * sizeof(double) : mh->off_chain;
+    HIP_TRY(hipMemcpyAsync(mh->d_pack, mh->h_pack, used, hipMemcpyHostToDevice, st), ctx, return SEPAIHRD_E_HIP);
+    int rc = 0;
+    if (accept) {
+        rc = sampler_commit(mh->st, mh->d_pack, mh->rows, st);
+        if (rc == 0) mh->rows++;
+    }
+    if (rc == 0) rc = mh_adapt_step(mh, gamma, adapt);
+    if (rc != 0) { ctx->last_error = "mh_step: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipStreamWaitEvent(st, mh->ev_staged, 0), ctx, return SEPAIHRD_E_HIP);  // the staged normals have landed
+    rc = sampler_patch_normals(mh->d_z_stage, reinterpret_cast<const int32_t*>(mh->d_pack + mh->off_chain),
+                               reinterpret_cast<const double*>(mh->d_pack + mh->off_rows), n_patch, P, st);
+    if (rc == 0) rc = sampler_propose(mh->st, ctx->dp, mh->d_z_stage, reinterpret_cast<const double*>(mh->d_pack + mh->off_scale), st);
+    if (rc != 0) { ctx->last_error = "mh_step: launch failed"; return SEPAIHRD_E_HIP; }
+    std::swap(mh->d_z, mh->d_z_stage);  // the next staging goes to the other buffer
+    mh->staged = false;
+    return sepaihrd_eval_batch_device(ctx, mh->st.prop, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 int sepaihrd_mh_fetch(sepaihrd_mh* mh, double* loglik, int32_t* status) {
@@ -1016,14 +1155,7 @@ int sepaihrd_mh_adapt(sepaihrd_mh* mh, double gamma, int refresh, int recompute_
     if (!mh) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    int rc = sampler_rank1(mh->st, gamma, mh->rows - 1, mh->stream);
-    if (rc == 0 && refresh) {
-        if (recompute_full) {
-            rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
-            if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, mh->stream);  // :190-197, kept on success
-        }
-        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);  // :295-300
-    }
+    const int rc = mh_adapt_step(mh, gamma, refresh ? (recompute_full ? 3 : 2) : 1);
     if (rc != 0) {
         ctx->last_error = "mh_adapt: launch failed";
         return SEPAIHRD_E_HIP;
@@ -1061,10 +1193,26 @@ int sepaihrd_mh_read_proposal(sepaihrd_mh* mh, double* prop) {
     return SEPAIHRD_OK;
 }
 
+int sepaihrd_mh_read_best(sepaihrd_mh* mh, double* best) {
+    if (!mh || !best) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(best, mh->st.best, (size_t)mh->st.C * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
+            return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_busy(sepaihrd_mh* mh) {
+    if (!mh) return 0;
+    return hipStreamQuery(mh->stream) == hipErrorNotReady ? 1 : 0;
+}
+
 int sepaihrd_mh_read_covariance(sepaihrd_mh* mh, double* cov) {
     if (!mh || !cov) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (mh_flush_rank1(mh) != 0) { ctx->last_error = "mh_read_covariance: rank-one catch-up failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpy(cov, mh->st.cov, (size_t)mh->st.C * mh->st.P * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
             return SEPAIHRD_E_HIP);

@@ -165,13 +165,16 @@ struct SamplerState {
     double* x;      // [C][P] current state
     double* prop;   // [C][P] last proposal (after applyConstraints)
     double* cov;    // [C][P][P] proposal covariance, row-major
-    double* chol;   // [C][P][P] its lower Cholesky factor
+    double* chol;   // [C][P][P] its lower Cholesky factor, column-major: L(i, j) at [j][i] (coalesced in the proposal)
     double* mean;   // [C][P] running mean
     double* hist;   // [C][capacity][P] every state of every chain
+    double* best;   // [C][P] the best state so far (updated by commit where bit 1 of the chain's accept byte is set)
 };
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
+int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_rows, int n_patch, int P, void* stream);
 int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream);
+int sampler_rank1_catchup(const SamplerState& s, const double* d_gammas, int row0, int n, void* stream);
 int sampler_full_covariance(const SamplerState& s, int len, void* stream);
 int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream);
 

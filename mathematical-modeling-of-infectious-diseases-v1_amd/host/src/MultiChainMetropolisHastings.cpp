@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +74,33 @@ int host_thread_share() {
     }
     if (const char* env = std::getenv("SEPAIHRD_CPU_THREADS")) n = std::max(1, std::min(n, std::atoi(env)));
     return std::max(1, n);
+}
+
+// std::normal_distribution<double>(0, 1) of libstdc++ (bits/random.tcc: Marsaglia polar method over
+// generate_canonical<double, 53>) written out for std::mt19937: the same words consumed in the same order, the same
+// double operations, so the same values -- without the long double arithmetic of generate_canonical and the
+// distribution object's state.  A FRESH distribution per proposal (generateProposal :93-97): pairs are produced as
+// (y mult, x mult) and the second value of the last pair is dropped when P is odd.  The device-resident loop below
+// draws with it; optimizeChains() keeps std::normal_distribution, and the tests require both to give the same chains.
+inline double canonical53(std::mt19937& g) {
+    const double lo = static_cast<double>(g());               // sum += (urng() - min) * 1
+    const double hi = static_cast<double>(g());               // sum += (urng() - min) * 2^32
+    double ret = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+    if (__builtin_expect(ret >= 1.0, 0)) ret = std::nextafter(1.0, 0.0);
+    return ret;
+}
+inline void draw_standard_normals(std::mt19937& g, double* dst, int P) {
+    for (int i = 0; i < P; i += 2) {
+        double x, y, r2;
+        do {
+            x = 2.0 * canonical53(g) - 1.0;
+            y = 2.0 * canonical53(g) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = std::sqrt(-2 * std::log(r2) / r2);
+        dst[i] = (y * mult) * 1.0 + 0.0;                       // ret * stddev + mean
+        if (i + 1 < P) dst[i + 1] = (x * mult) * 1.0 + 0.0;   // the saved value
+    }
 }
 
 inline double sanitize(double v) { return (std::isnan(v) || std::isinf(v)) ? -1e18 : v; }  // safeEvaluate :65-74
@@ -354,25 +382,25 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     struct Light {
         std::mt19937 gen[2];  // gen[cur]: the chain's stream; gen[1 - cur]: its copy that already drew the uniform
         int cur = 0;
-        double u = 0.0;       // the uniform of the branch that draws it
+        double log_u = 0.0;   // log of the uniform of the branch that draws it
         double lp = 0.0, log_scale = 0.0, scale = 1.0, best = 0.0;
         std::vector<unsigned char> recent;  // ring of the last 1000 accept flags (:107-110) + their sum
         size_t recent_pos = 0, recent_len = 0;
         int recent_sum = 0;
         int emergency = 0, accepted = 0;
+        double cand_log_scale[2] = {0.0, 0.0}, cand_scale[2] = {1.0, 1.0};  // adaptGlobalScale for reject / accept, prepared ahead
         std::vector<double> best_x;
         std::vector<double> sample_values;
     };
     std::vector<Light> chains(static_cast<size_t>(C));
     const size_t CP = static_cast<size_t>(C) * P;
-    std::vector<double> values(static_cast<size_t>(C)), scale(static_cast<size_t>(C)), prop(CP);
-    // the normals of the proposal being evaluated (z) and of the next one (z_next): the roles swap every iteration,
-    // nothing is copied
-    std::vector<double> z_buffers[2] = {std::vector<double>(CP), std::vector<double>(CP)};
-    double* z = z_buffers[0].data();
-    double* z_next = z_buffers[1].data();
+    std::vector<double> values(static_cast<size_t>(C)), scale(static_cast<size_t>(C));
+    std::vector<double> z_alt(CP);                  // the other branch's normals, drawn for as many chains as the wait allows
+    std::vector<uint8_t> alt_ready(static_cast<size_t>(C));
+    double* z_next = sepaihrd_mh_staging_buffer(mh);  // page-locked; re-fetched after every staging (two alternate)
+    std::vector<int32_t> patch_chain(static_cast<size_t>(C));
     std::vector<int32_t> status(static_cast<size_t>(C));
-    std::vector<uint8_t> accept(static_cast<size_t>(C));
+    std::vector<uint8_t> accept(static_cast<size_t>(C)), needs_patch(static_cast<size_t>(C));
     auto sanitize_all = [&]() {
         for (int c = 0; c < C; ++c)
             values[static_cast<size_t>(c)] = status[static_cast<size_t>(c)] >= 2 ? -1e18 : sanitize(values[static_cast<size_t>(c)]);
@@ -382,9 +410,31 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     traces_.assign(static_cast<size_t>(C), {});
     std::vector<int32_t> sample_rows;
     if (store_samples_) sample_rows.push_back(0);
-    auto draw_normals = [P](std::mt19937& g, double* dst) {  // generateProposal :91-102: a fresh distribution per proposal
-        std::normal_distribution<double> dist(0.0, 1.0);
-        for (int i = 0; i < P; ++i) dst[i] = dist(g);
+    auto draw_normals = [P](std::mt19937& g, double* dst) { draw_standard_normals(g, dst, P); };  // generateProposal :91-102
+    // adaptGlobalScale (:104-152) as a function of the accept flag: the new log-scale, without touching the chain.
+    // Evaluated twice per chain AHEAD of the accept test (while the device works) so that the exp() of the branch
+    // taken is ready, and once more in the test itself for the ring bookkeeping -- same arithmetic both times.
+    const double target = target_acceptance_rate_;
+    auto next_log_scale = [target](const Light& ch, bool acc, int t, bool* emergency_hit) -> double {
+        size_t len = ch.recent_len;
+        int sum = ch.recent_sum;
+        if (len == 1000) sum -= ch.recent[ch.recent_pos]; else ++len;
+        sum += acc ? 1 : 0;
+        const double rate = static_cast<double>(sum) / static_cast<double>(len);
+        double ls = ch.log_scale;
+        *emergency_hit = false;
+        if (len >= 1000 && rate < 0.001) { ls -= 0.7; *emergency_hit = true; }
+        else if (rate < 0.02 && len >= 500) {
+            double g = 5.0 / std::sqrt(static_cast<double>(t) + 1.0);
+            g = std::min(g, 0.3);
+            ls += g * (0.0 - target);
+        } else {
+            double g = 1.0 / std::sqrt(static_cast<double>(t) + 1.0);
+            g = std::min(g, 0.1);
+            ls += g * ((acc ? 1.0 : 0.0) - target);
+        }
+        if (ch.scale <= 0.011 && rate > 0.15 && rate < 0.30) ls += 0.01;
+        return std::max(std::min(ls, 2.3), -6.9);
     };
 #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int c = 0; c < C; ++c) {
@@ -395,38 +445,75 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         ch.recent.assign(1000, 0);
         if (store_samples_) ch.sample_values.push_back(ch.lp);
         traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
-        draw_normals(ch.gen[0], &z[static_cast<size_t>(c) * P]);  // proposal 1
+        draw_normals(ch.gen[0], &z_next[static_cast<size_t>(c) * P]);  // proposal 1
         scale[static_cast<size_t>(c)] = ch.scale;
     }
 
     const bool profile = std::getenv("SEPAIHRD_MH_PROFILE") != nullptr;
-    double t_launch = 0, t_spec = 0, t_wait = 0, t_acc = 0, t_commit = 0;
+    double t_launch = 0, t_spec = 0, t_wait = 0, t_acc = 0, t_alt = 0;
+    long alt_drawn = 0, alt_used = 0, alt_missing = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double>(b - a).count();
     };
+    // adaptation step that precedes proposal t (:279-301; the history then holds t rows, states 0 .. t-1)
+    auto adapt_mode = [&](int t) -> int {
+        if (t <= burn_in_) return 0;
+        if (t % adaptation_period_ != 0) return 1;
+        return static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 3 : 2;
+    };
+    if (iterations_ > 1) {  // proposal 1: nothing to commit yet
+        check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
+        z_next = sepaihrd_mh_staging_buffer(mh);
+        check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
+    }
     for (int t = 1; t < iterations_; ++t) {
-        const auto p0 = now();
-        if (t > burn_in_) {  // :279-301; the history holds t rows (states 0 .. t-1)
-            const bool refresh = (t % adaptation_period_ == 0);
-            check(sepaihrd_mh_adapt(mh, 10.0 / (t + 100.0), refresh ? 1 : 0, static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 1 : 0),
-                  "mh_adapt");
-        }
-        check(sepaihrd_mh_propose(mh, z, scale.data(), nullptr, nullptr), "mh_propose");  // launch only
         const auto p1 = now();
         const bool more = t + 1 < iterations_;
-        if (more) {
+        // ---- while the device evaluates proposal t: everything of the accept test and of proposal t + 1 that does not
+        //      need the values -- the uniform of the likely branch and its log, the normals that follow it in the
+        //      stream, both outcomes of the scale adaptation with their exp()
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-            for (int c = 0; c < C; ++c) {
-                // draws of proposal t+1 for the LIKELY outcome of this iteration's accept test (log_ratio < 0:
-                // the uniform is drawn first); the other outcome's draws are made after the test, for the
-                // chains that need them
-                Light& ch = chains[static_cast<size_t>(c)];
-                std::mt19937& with_u = ch.gen[1 - ch.cur];
-                with_u = ch.gen[ch.cur];
-                std::uniform_real_distribution<double> u_dist(0.0, 1.0);
-                ch.u = u_dist(with_u);
-                draw_normals(with_u, &z_next[static_cast<size_t>(c) * P]);
+        for (int c = 0; c < C; ++c) {
+            Light& ch = chains[static_cast<size_t>(c)];
+            std::mt19937& with_u = ch.gen[1 - ch.cur];
+            with_u = ch.gen[ch.cur];
+            std::uniform_real_distribution<double> u_dist(0.0, 1.0);
+            ch.log_u = std::log(u_dist(with_u));                                   // :327
+            if (more) draw_normals(with_u, &z_next[static_cast<size_t>(c) * P]);
+            if (adapt_scale_) {
+                bool e;
+                for (int a = 0; a < 2; ++a) {
+                    ch.cand_log_scale[a] = next_log_scale(ch, a == 1, t, &e);
+                    ch.cand_scale[a] = std::exp(ch.cand_log_scale[a]);
+                }
+            }
+        }
+        if (more) {  // lands while the evaluation runs
+            check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
+            z_next = sepaihrd_mh_staging_buffer(mh);
+        }
+        const auto p2a = now();
+        // The device is usually still busy: use the wait to draw the OTHER branch's normals (the stream without the
+        // uniform) chain by chain until the evaluation is done.  A chain that turns out to need them finds them ready
+        // (and its stream advanced exactly as the late draw would have); the others discard them with the stream copy.
+        std::fill(alt_ready.begin(), alt_ready.end(), 0);
+        if (more) {
+            std::atomic<bool> stop{false};
+#pragma omp parallel num_threads(nthreads)
+            {
+#ifdef _OPENMP
+                const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+                const int tid = 0, nt = 1;
+#endif
+                for (int c = tid; c < C; c += nt) {
+                    if (tid == 0 && (c / nt) % 4 == 0 && !sepaihrd_mh_busy(mh)) stop.store(true, std::memory_order_relaxed);
+                    if (stop.load(std::memory_order_relaxed)) break;
+                    Light& ch = chains[static_cast<size_t>(c)];
+                    draw_normals(ch.gen[ch.cur], &z_alt[static_cast<size_t>(c) * P]);
+                    alt_ready[static_cast<size_t>(c)] = 1;
+                }
             }
         }
         const auto p2 = now();
@@ -440,68 +527,68 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             const double prop_lp = values[static_cast<size_t>(c)];
             const double log_ratio = prop_lp - ch.lp;
             bool acc = false;
+            needs_patch[static_cast<size_t>(c)] = 0;
             if (log_ratio >= 0.0) {
-                acc = true;
-                if (more) draw_normals(ch.gen[ch.cur], &z_next[static_cast<size_t>(c) * P]);  // the stream without the uniform
+                acc = true;  // no uniform drawn: the next normals come from the untouched stream
+                needs_patch[static_cast<size_t>(c)] = more ? 1 : 0;
+                if (more && !alt_ready[static_cast<size_t>(c)]) draw_normals(ch.gen[ch.cur], &z_alt[static_cast<size_t>(c) * P]);
             } else {
-                double u = ch.u;
-                if (!more) {  // no speculation ran for the last iteration
-                    std::uniform_real_distribution<double> u_dist(0.0, 1.0);
-                    u = u_dist(ch.gen[ch.cur]);
-                } else {
-                    ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one; its normals are in z_next
-                }
-                if (std::log(u) < log_ratio) acc = true;
+                ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one; its normals are staged
+                if (ch.log_u < log_ratio) acc = true;
             }
             accept[static_cast<size_t>(c)] = acc ? 1 : 0;
             if (acc) {
                 ch.lp = prop_lp;
                 ch.accepted++;
-                if (ch.lp > ch.best) { ch.best = ch.lp; ch.best_x.clear(); any_best = true; }  // filled below
+                if (ch.lp > ch.best) { ch.best = ch.lp; accept[static_cast<size_t>(c)] |= 2; any_best = true; }  // the device keeps the state
             }
             traces_[static_cast<size_t>(c)].push_back(acc ? 1 : 0);
             if (adapt_scale_) {  // adaptGlobalScale :104-152
+                bool emergency_hit;
+                const double ls = next_log_scale(ch, acc, t, &emergency_hit);
                 if (ch.recent_len == 1000) ch.recent_sum -= ch.recent[ch.recent_pos]; else ch.recent_len++;
                 ch.recent[ch.recent_pos] = acc ? 1 : 0;
                 ch.recent_sum += acc ? 1 : 0;
                 ch.recent_pos = (ch.recent_pos + 1) % 1000;
-                const double rate = static_cast<double>(ch.recent_sum) / ch.recent_len;
-                if (ch.recent_len >= 1000 && rate < 0.001) { ch.log_scale -= 0.7; ch.emergency++; }
-                else if (rate < 0.02 && ch.recent_len >= 500) {
-                    double g = 5.0 / std::sqrt(static_cast<double>(t) + 1.0);
-                    g = std::min(g, 0.3);
-                    ch.log_scale += g * (0.0 - target_acceptance_rate_);
-                } else {
-                    double g = 1.0 / std::sqrt(static_cast<double>(t) + 1.0);
-                    g = std::min(g, 0.1);
-                    ch.log_scale += g * ((acc ? 1.0 : 0.0) - target_acceptance_rate_);
-                }
-                if (ch.scale <= 0.011 && rate > 0.15 && rate < 0.30) ch.log_scale += 0.01;
-                ch.log_scale = std::max(std::min(ch.log_scale, 2.3), -6.9);
-                ch.scale = std::exp(ch.log_scale);
+                if (emergency_hit) ch.emergency++;
+                ch.log_scale = ls;
+                ch.scale = (ls == ch.cand_log_scale[acc ? 1 : 0]) ? ch.cand_scale[acc ? 1 : 0] : std::exp(ls);
             }
             scale[static_cast<size_t>(c)] = ch.scale;
             if (store_samples_ && (t % thinning_ == 0)) ch.sample_values.push_back(ch.lp);
         }
-        if (any_best) {  // a chain improved its best state: fetch the proposals once
-            check(sepaihrd_mh_read_proposal(mh, prop.data()), "mh_read_proposal");
-            for (int c = 0; c < C; ++c) {
-                Light& ch = chains[static_cast<size_t>(c)];
-                if (ch.best_x.empty())
-                    ch.best_x.assign(prop.begin() + static_cast<size_t>(c) * P, prop.begin() + static_cast<size_t>(c + 1) * P);
-            }
-        }
-        std::swap(z, z_next);
+        // the rows of the staged normals that belong to the other branch (in z_alt, drawn ahead or just now): their list
+        int n_patch = 0;
+        if (more)
+            for (int c = 0; c < C; ++c)
+                if (needs_patch[static_cast<size_t>(c)]) patch_chain[static_cast<size_t>(n_patch++)] = c;
         const auto p4 = now();
-        check(sepaihrd_mh_commit(mh, accept.data()), "mh_commit");
-        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
+        (void)any_best;
         const auto p5 = now();
-        t_launch += secs(p0, p1); t_spec += secs(p1, p2); t_wait += secs(p2, p3); t_acc += secs(p3, p4); t_commit += secs(p4, p5);
+        if (more)  // commit t, adapt, propose t + 1 and launch its evaluation: one call, one upload
+            check(sepaihrd_mh_step(mh, accept.data(), scale.data(), patch_chain.data(), z_alt.data(), n_patch,
+                                   10.0 / ((t + 1) + 100.0), adapt_mode(t + 1)), "mh_step");
+        else
+            check(sepaihrd_mh_commit(mh, accept.data()), "mh_commit");
+        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
+        const auto p6 = now();
+        t_spec += secs(p1, p2a); t_alt += secs(p2a, p2); t_wait += secs(p2, p3); t_acc += secs(p3, p4); t_launch += secs(p5, p6);
+        if (profile)
+            for (int c = 0; c < C; ++c) {
+                alt_drawn += alt_ready[static_cast<size_t>(c)];
+                if (needs_patch[static_cast<size_t>(c)]) { if (alt_ready[static_cast<size_t>(c)]) ++alt_used; else ++alt_missing; }
+            }
+    }
+    {   // the best states were kept on the device
+        std::vector<double> best_all(CP);
+        check(sepaihrd_mh_read_best(mh, best_all.data()), "mh_read_best");
+        for (int c = 0; c < C; ++c)
+            chains[static_cast<size_t>(c)].best_x.assign(best_all.begin() + static_cast<size_t>(c) * P, best_all.begin() + static_cast<size_t>(c + 1) * P);
     }
     if (profile)
-        std::fprintf(stderr, "[mh profile] per iteration ms: copies+launch %.3f  draws for t+1 (overlapped) %.3f  wait for device %.3f  accept %.3f  commit %.3f\n",
-                     1e3 * t_launch / iterations_, 1e3 * t_spec / iterations_, 1e3 * t_wait / iterations_, 1e3 * t_acc / iterations_,
-                     1e3 * t_commit / iterations_);
+        std::fprintf(stderr, "[mh profile] per iteration ms: prepared during the evaluation %.3f  other-branch draws while waiting %.3f  wait for device %.3f  accept + re-draws %.3f  upload + launches %.3f; other-branch rows per iteration: drawn ahead %.0f, used %.0f, drawn late %.0f\n",
+                     1e3 * t_spec / iterations_, 1e3 * t_alt / iterations_, 1e3 * t_wait / iterations_, 1e3 * t_acc / iterations_,
+                     1e3 * t_launch / iterations_, (double)alt_drawn / iterations_, (double)alt_used / iterations_, (double)alt_missing / iterations_);
 
     std::vector<double> rows, covs(static_cast<size_t>(C) * PP);
     const int ns = static_cast<int>(sample_rows.size());
