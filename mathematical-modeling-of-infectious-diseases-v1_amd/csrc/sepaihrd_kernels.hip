@@ -241,6 +241,109 @@ __device__ __forceinline__ double pow_ctl(double x, double c) {
 #endif
 }
 
+#if SEPAIHRD_ARITH_FMA
+// Stage coefficients through DPP (tolerance build).  Every stage sum multiplies the chain's step `cur` by tableau
+// constants: 26 v_mul_f64 per attempt, each constant a 64-bit literal that has to sit in (or be re-materialised into)
+// an SGPR pair.  A chain is a 16-lane DPP row here, so lane l of the row computes cur * coefficient[l] ONCE (two
+// multiplications fill two 16-entry vectors) and every term of a stage sum after the first takes its factor from there
+// as the row_newbcast source of the v_fmac_f64_dpp that adds the term: the broadcast costs nothing.  The first term of a
+// sum (x + f1 k1: a three-operand fma) and the two leading products of the error estimate keep their own per-lane
+// factor.  Same products, same fmas, same order as written out term by term (and as the 4-lane kernel): same bits.
+enum QuadCoefDopri5 { QD_B32 = 0, QD_B42, QD_B43, QD_B52, QD_B53, QD_B54, QD_B62, QD_B63, QD_B64, QD_B65, QD_C3, QD_C4, QD_C5,
+                      QD_C6, QD_DC4, QD_DC5, QD_DC6 /* vector B lane 0 */, QD_DC7 /* vector B lane 1 */ };
+enum QuadCoefCashKarp { QK_A32 = 0, QK_A42, QK_A43, QK_A52, QK_A53, QK_A54, QK_A62, QK_A63, QK_A64, QK_A65, QK_B3, QK_B4, QK_B6,
+                        QK_DB4, QK_DB5, QK_DB6 };
+__device__ const double QUAD_COEF[2][2][16] = {
+    {{dp::b32, dp::b42, dp::b43, dp::b52, dp::b53, dp::b54, dp::b62, dp::b63, dp::b64, dp::b65, dp::c3, dp::c4, dp::c5, dp::c6,
+      dp::dc4, dp::dc5},
+     {dp::dc6, dp::dc7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
+    {{ck::a32, ck::a42, ck::a43, ck::a52, ck::a53, ck::a54, ck::a62, ck::a63, ck::a64, ck::a65, ck::b3, ck::b4, ck::b6, ck::db4,
+      ck::db5, ck::db6},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+// acc += (cur * coefficient IDX of the chain's row) * k
+template <int IDX>
+__device__ __forceinline__ void stage_term(double& acc, double vecA, double vecB, double k) {
+    if constexpr (IDX < 16) fmac_row_bcast<IDX, 0xf, false>(acc, vecA, k);
+    else fmac_row_bcast<IDX - 16, 0xf, false>(acc, vecB, k);
+}
+
+
+// The RK stages of one attempt with the row-coefficient vectors: k2..k7 (k1 for Cash-Karp), the new state and the
+// error estimate.  rhs_call(x_in, k_out, beta_kappa) evaluates the right-hand side.  N = values per lane.
+template <int SOLVER, int N, class RHS>
+__device__ __forceinline__ void rk_stages_row_coef(const double cur, const double vecA, const double vecB, const double (&x)[N],
+                                                   double (&k1)[N], double (&k2)[N], double (&k3)[N], double (&k4)[N], double (&k5)[N],
+                                                   double (&k6)[N], double (&k7)[N], double (&xnew)[N], double (&xerr)[N],
+                                                   const double (&bks)[7], RHS&& rhs_call) {
+    double xt[N];
+        if (SOLVER == 0) {
+            { const double f1 = cur * dp::b21;
+              SEP_UNROLL for (int c = 0; c < N; ++c) xt[c] = fma(f1, k1[c], x[c]);
+              rhs_call(xt, k2, bks[1]); }
+            { const double f1 = cur * dp::b31;
+              SEP_UNROLL for (int c = 0; c < N; ++c) { xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B32>(xt[c], vecA, vecB, k2[c]); }
+              rhs_call(xt, k3, bks[2]); }
+            { const double f1 = cur * dp::b41;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B42>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B43>(xt[c], vecA, vecB, k3[c]); }
+              rhs_call(xt, k4, bks[3]); }
+            { const double f1 = cur * dp::b51;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B52>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B53>(xt[c], vecA, vecB, k3[c]);
+                  stage_term<QD_B54>(xt[c], vecA, vecB, k4[c]); }
+              rhs_call(xt, k5, bks[4]); }
+            { const double f1 = cur * dp::b61;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B62>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B63>(xt[c], vecA, vecB, k3[c]);
+                  stage_term<QD_B64>(xt[c], vecA, vecB, k4[c]); stage_term<QD_B65>(xt[c], vecA, vecB, k5[c]); }
+              rhs_call(xt, k6, bks[5]); }
+            { const double f1 = cur * dp::c1;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xnew[c] = fma(f1, k1[c], x[c]); stage_term<QD_C3>(xnew[c], vecA, vecB, k3[c]); stage_term<QD_C4>(xnew[c], vecA, vecB, k4[c]);
+                  stage_term<QD_C5>(xnew[c], vecA, vecB, k5[c]); stage_term<QD_C6>(xnew[c], vecA, vecB, k6[c]); }
+              rhs_call(xnew, k7, bks[6]); }
+            // e1 k1 + e3 k3 + ...: of two leading products the contraction pass rounds the second and fuses the first
+            // (see the 4-lane kernel's listing); written out so that it does not depend on the pass
+            { const double e1 = cur * dp::dc1, e3 = cur * dp::dc3;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xerr[c] = fma(e1, k1[c], e3 * k3[c]); stage_term<QD_DC4>(xerr[c], vecA, vecB, k4[c]); stage_term<QD_DC5>(xerr[c], vecA, vecB, k5[c]);
+                  stage_term<QD_DC6>(xerr[c], vecA, vecB, k6[c]); stage_term<QD_DC7>(xerr[c], vecA, vecB, k7[c]); } }
+        } else {
+            rhs_call(x, k1, bks[0]);
+            { const double f1 = ck::a21 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) xt[c] = fma(f1, k1[c], x[c]);
+              rhs_call(xt, k2, bks[1]); }
+            { const double f1 = ck::a31 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) { xt[c] = fma(f1, k1[c], x[c]); stage_term<QK_A32>(xt[c], vecA, vecB, k2[c]); }
+              rhs_call(xt, k3, bks[2]); }
+            { const double f1 = ck::a41 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QK_A42>(xt[c], vecA, vecB, k2[c]); stage_term<QK_A43>(xt[c], vecA, vecB, k3[c]); }
+              rhs_call(xt, k4, bks[3]); }
+            { const double f1 = ck::a51 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QK_A52>(xt[c], vecA, vecB, k2[c]); stage_term<QK_A53>(xt[c], vecA, vecB, k3[c]);
+                  stage_term<QK_A54>(xt[c], vecA, vecB, k4[c]); }
+              rhs_call(xt, k5, bks[4]); }
+            { const double f1 = ck::a61 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xt[c] = fma(f1, k1[c], x[c]); stage_term<QK_A62>(xt[c], vecA, vecB, k2[c]); stage_term<QK_A63>(xt[c], vecA, vecB, k3[c]);
+                  stage_term<QK_A64>(xt[c], vecA, vecB, k4[c]); stage_term<QK_A65>(xt[c], vecA, vecB, k5[c]); }
+              rhs_call(xt, k6, bks[5]); }
+            { const double f1 = ck::b1 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xnew[c] = fma(f1, k1[c], x[c]); stage_term<QK_B3>(xnew[c], vecA, vecB, k3[c]); stage_term<QK_B4>(xnew[c], vecA, vecB, k4[c]);
+                  stage_term<QK_B6>(xnew[c], vecA, vecB, k6[c]); } }
+            // here the pass rounds the FIRST product and fuses the second (it rounds the one whose coefficient is
+            // negative: db1 < 0 < db3, while dc3 < 0 < dc1 above)
+            { const double e1 = ck::db1 * cur, e3 = ck::db3 * cur;
+              SEP_UNROLL for (int c = 0; c < N; ++c) {
+                  xerr[c] = fma(e3, k3[c], e1 * k1[c]); stage_term<QK_DB4>(xerr[c], vecA, vecB, k4[c]); stage_term<QK_DB5>(xerr[c], vecA, vecB, k5[c]);
+                  stage_term<QK_DB6>(xerr[c], vecA, vecB, k6[c]); } }
+        }
+}
+#endif
+
 // ----------------------------------------------------------------------------------
 // the evaluation kernel: block = one wavefront = 64/LPC chains
 // ----------------------------------------------------------------------------------
@@ -477,6 +580,11 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     }
 
     const double eps_abs = pb.abs_tol, eps_rel = pb.rel_tol;
+#if SEPAIHRD_ARITH_FMA
+    // sixteen lanes per chain = one DPP row per chain: the stage coefficients come as row broadcasts (see QUAD_COEF)
+    constexpr bool ROW_COEF = (LPC == 16);
+    const double coefA = ROW_COEF ? QUAD_COEF[SOLVER][0][lane & 15] : 0.0, coefB = ROW_COEF ? QUAD_COEF[SOLVER][1][lane & 15] : 0.0;
+#endif
 
 #ifdef SEPAIHRD_STAMPS
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
@@ -487,6 +595,11 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         SEP_STAMP(st0);
         // min_abs(dt, t_next - t); finished chains idle with a harmless unit step
         const double cur = active ? fmin(dt, t_next - t) : 1.0;
+#if SEPAIHRD_ARITH_FMA
+        double vecA = 0.0, vecB = 0.0;
+        if constexpr (ROW_COEF)
+            asm("v_mul_f64 %0, %2, %3\n\tv_mul_f64 %1, %2, %4\n\ts_nop 1" : "=&v"(vecA), "=&v"(vecB) : "v"(cur), "v"(coefA), "v"(coefB));
+#endif
 
         // stage times and beta*kappa at those times
         double tau[7], bks[7];
@@ -534,6 +647,12 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         double xt[NUM_COMP], xnew[NUM_COMP], xerr[NUM_COMP];
         double k7[NUM_COMP];
 
+#if SEPAIHRD_ARITH_FMA
+        if constexpr (ROW_COEF) {
+            rk_stages_row_coef<SOLVER, NUM_COMP>(cur, vecA, vecB, x, k1, k2, k3, k4, k5, k6, k7, xnew, xerr, bks,
+                                                 [&](const double (&xin)[NUM_COMP], double (&kout)[NUM_COMP], double bk) { rhs<LPC>(q, xin, kout, bk); });
+        } else
+#endif
         if (SOLVER == 0) {
             // runge_kutta_dopri5::do_step_impl -- scale_sumN left to right, factors dt*b
             { const double f1 = cur * dp::b21;
