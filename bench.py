@@ -44,8 +44,8 @@ PARITY_NOTES = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c5"], default="c1",
                     help="BASELINE.json configs: c1 = configs[1] (default), c2 = Cash-Karp 65 536 chains, "
                          "c3 = 32 768 chains/GPU, c5 = 16 age groups x 1 000 days")
@@ -355,7 +355,7 @@ def main():
             try:
                 with open(traffic_src) as fh:
                     tj = json.load(fh)
-                key = f"{args.workload}_{solver_name}_{args.arith}_B{B}"
+                key = f"{args.workload}_{solver_name}_{args.arith if args.precision == 'f64' else 'f32'}_B{B}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
