@@ -343,7 +343,8 @@ def main():
         # csrc/sepaihrd_device.h split_likelihood(): batches that do not fill the chip, and Dopri5 in tolerance mode at
         # any size, park the daily increments for a separate likelihood pass
         waves4 = -(-B // (64 // max(1, 1 << (pb.n - 1).bit_length())))
-        split_ll = (waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)) and args.precision == "f64"
+        split_ll = ((waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)) and args.precision == "f64"
+                    and "+ll" not in info["kernel_name"])  # "+ll": likelihood on consumer waves of the integrator's workgroup, nothing parked
         ws_bytes_eval = pb.n_times * 3 * pb.n * 8 if split_ll else 0
         bytes_launch = bytes_eval * B
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
