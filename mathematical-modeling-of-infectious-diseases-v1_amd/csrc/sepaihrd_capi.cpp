@@ -62,6 +62,8 @@ struct sepaihrd_ctx {
     bool busy_valid = false;
     // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
     bool timing = false;
+    int timing_period = 1;     // events around every timing_period-th launch sequence only
+    long timing_seen = 0;
     std::vector<hipEvent_t> ev;  // triples: before integrator, after integrator, after likelihood pass
     size_t ev_used = 0;
 };
@@ -487,7 +489,7 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
     for (size_t off = 0; off < (size_t)B; off += chunk) {
         const int nb = (int)std::min(chunk, (size_t)B - off);
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-        if (ctx->timing) {
+        if (ctx->timing && (ctx->timing_seen++ % ctx->timing_period) == 0) {
             while (ctx->ev.size() < ctx->ev_used + 3) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e), ctx, return SEPAIHRD_E_HIP);
@@ -523,6 +525,8 @@ int sepaihrd_eval_batch_device(sepaihrd_ctx* ctx, const double* d_theta, int B, 
 int sepaihrd_set_timing(sepaihrd_ctx* ctx, int enable) {
     if (!ctx) return SEPAIHRD_E_INVALID_ARG;
     ctx->timing = enable != 0;
+    ctx->timing_period = enable > 1 ? enable : 1;
+    ctx->timing_seen = 0;
     ctx->ev_used = 0;
     return SEPAIHRD_OK;
 }

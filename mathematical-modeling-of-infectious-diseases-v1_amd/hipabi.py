@@ -248,7 +248,8 @@ class HipObjective:
                                                  addr(d_traj), stream if stream else None)
         self._check(rc, "sepaihrd_eval_batch_device")
 
-    def set_timing(self, enable: bool):
+    def set_timing(self, enable):
+        """True / 1: events around every launch; k > 1: around every k-th launch; False / 0: off."""
         self._check(self.lib.sepaihrd_set_timing(self.ctx, int(enable)), "sepaihrd_set_timing")
 
     def get_timing(self) -> dict:
