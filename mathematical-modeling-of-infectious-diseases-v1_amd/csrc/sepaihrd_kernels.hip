@@ -1022,6 +1022,9 @@ inline bool lane_split_wanted(int B) {
     }();
     return mode < 0 ? B <= QUAD_MAX_CHAINS : mode != 0;
 }
+#if SEPAIHRD_ARITH_FMA
+#include "sepaihrd_wave_chain.inc"  // one wavefront per chain: the latency form for batches of up to WAVE_CHAIN_MAX chains
+#endif
 
 // ----------------------------------------------------------------------------------
 // launch plumbing
@@ -1058,6 +1061,11 @@ int needs_workspace_one(const DevProblem& pb, int B, int force_split) {
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
+#if SEPAIHRD_ARITH_FMA
+    if constexpr (LPC == 4) {
+        if (wave_chain_wanted(B)) return 1;  // the one-wave-per-chain form parks its increments
+    }
+#endif
     if constexpr (LPC == 4) {
         // the 16-lane form evaluates the likelihood on consumer waves of the same workgroup: no workspace
         if (lane_split_wanted(B)) return (quad_fused_wanted() && !force_split && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS) ? 0 : 1;
@@ -1070,6 +1078,11 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
+#if SEPAIHRD_ARITH_FMA
+    if constexpr (LPC == 4) {
+        if (wave_chain_wanted(B)) return launch_wave_chain<SOLVER>(pb, d_theta, B, out, stream);
+    }
+#endif
     if constexpr (LPC == 4) {
         if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
@@ -1102,6 +1115,12 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
 
 template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
+#if SEPAIHRD_ARITH_FMA
+    if constexpr (LPC == 4) {
+        if (batch > 0 && wave_chain_wanted(batch))
+            return info_of(&sepaihrd_eval_wave_kernel<SOLVER>, pb, WAVE, info, "sepaihrd_eval_wave_kernel[fma]", WAVE, wave_chain_lds_bytes(pb));
+    }
+#endif
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(batch))
             return quad_fused_wanted() ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", 8 * WAVE, quad_fused_lds_bytes(pb))

@@ -347,7 +347,8 @@ def test_minimal_problem_one_parameter_no_schedule(mm, oracle_py, ref_fixture):
 def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains, arith):
     """Up to 4096 chains a 4-age problem runs the 16-lanes-per-chain form of the integrator
     (csrc/sepaihrd_lane_split.inc), in both arithmetic builds; SEPAIHRD_LANE_SPLIT=0 keeps the 4-lane kernel.  Same
-    chains through both, in two processes (the switch is read once): log-likelihood, status, step counts and every
+    chains through both (and, in the tolerance build, through the one-wavefront-per-chain kernel of
+    csrc/sepaihrd_wave_chain.inc), in separate processes (the switches are read once): log-likelihood, status, step counts and every
     trajectory state are the same bits -- a chain's result does not depend on the batch it was evaluated in.
     1021 and 37 chains leave a ragged last wave in both layouts."""
     import subprocess
@@ -356,7 +357,9 @@ def test_small_batch_kernel_gives_the_same_bits(problem, solver, chains, arith):
     r = subprocess.run([sys.executable, tool, "--problem", problem, "--solver", str(solver), "--chains", str(chains),
                         "--arith", arith], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "traj: identical=True" in r.stdout and "n_accept: identical=True" in r.stdout
+    assert "16-lane traj: identical=True" in r.stdout and "16-lane n_accept: identical=True" in r.stdout
+    if arith == "fma":
+        assert "wave-per-chain traj: identical=True" in r.stdout and "wave-per-chain loglik: identical=True" in r.stdout
 
 
 @pytest.mark.gpu

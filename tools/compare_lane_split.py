@@ -67,39 +67,43 @@ if __name__ == "__main__":
         child(a)
         sys.exit(0)
     outs = []
-    for mode in ("0", "1"):
-        out = f"/tmp/lane_split_{mode}.npz"
-        env = dict(os.environ, SEPAIHRD_LANE_SPLIT=mode)
+    # 4-lane kernel, 16-lane form, and (tolerance build only) the one-wavefront-per-chain form
+    variants = [("0", "0"), ("1", "0")] + ([("1", "2")] if a.arith == "fma" else [])
+    for mode, wave in variants:
+        out = f"/tmp/lane_split_{mode}{wave}.npz"
+        env = dict(os.environ, SEPAIHRD_LANE_SPLIT=mode, SEPAIHRD_WAVE_CHAIN=wave)
         subprocess.run([sys.executable, __file__, "--solver", str(a.solver), "--chains", str(a.chains), "--out", out, "--problem", a.problem, "--arith", a.arith, "--fuzz", str(a.fuzz), "--fuzz-cases", str(a.fuzz_cases),
                         "--one-step", str(a.one_step)],
                        env=env, check=True)
         outs.append(np.load(out))
     all_same = True
-    for k in outs[0].files:
-        x, y = outs[0][k], outs[1][k]
-        if k.endswith("traj"):  # rows after the point where a chain stopped (status != 0) are never written
-            ok = outs[0][k[:-4] + "status"] == 0
-            x, y = x[ok], y[ok]
-        same = np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
-        all_same &= bool(same)
-        msg = f"{k}: identical={same}"
-        if not same and x.dtype.kind == "f":
-            rel = np.abs(x - y) / np.maximum(np.abs(x), 1e-300)
-            msg += f" differing={int((x != y).sum())}/{x.size} max_rel={rel.max():.3e}"
-        elif not same:
-            msg += f" differing={int((x != y).sum())}/{x.size} max_abs={np.abs(x - y).max()}"
-        if not (a.fuzz and same):
-            print(msg)
-        if k == "traj" and not same and not a.fuzz:
-            d = (x != y)
-            tfirst = np.argmax(d.any(axis=(0, 2)))
-            print("first differing output index:", tfirst, "components (c*n+age):", np.unique(np.nonzero(d[:, tfirst, :])[1])[:44])
-            ch = np.nonzero(d[:, tfirst, :])[0][0]
-            n = x.shape[2] // 11
-            for c in range(11):
-                dd = d[:, tfirst, c * n:(c + 1) * n]
-                print("  comp", c, "differing", int(dd.sum()), "of", dd.size, "n_accept", outs[0]["n_accept"][:4])
-            print("chain", ch, "values", x[ch, tfirst, d[ch, tfirst]][:6], y[ch, tfirst, d[ch, tfirst]][:6])
+    for other in range(1, len(outs)):
+        tag = "16-lane" if other == 1 else "wave-per-chain"
+        for k in outs[0].files:
+            x, y = outs[0][k], outs[other][k]
+            if k.endswith("traj"):  # rows after the point where a chain stopped (status != 0) are never written
+                ok = outs[0][k[:-4] + "status"] == 0
+                x, y = x[ok], y[ok]
+            same = np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+            all_same &= bool(same)
+            msg = f"{tag} {k}: identical={same}"
+            if not same and x.dtype.kind == "f":
+                rel = np.abs(x - y) / np.maximum(np.abs(x), 1e-300)
+                msg += f" differing={int((x != y).sum())}/{x.size} max_rel={rel.max():.3e}"
+            elif not same:
+                msg += f" differing={int((x != y).sum())}/{x.size} max_abs={np.abs(x - y).max()}"
+            if not (a.fuzz and same):
+                print(msg)
+            if k == "traj" and not same and not a.fuzz:
+                d = (x != y)
+                tfirst = np.argmax(d.any(axis=(0, 2)))
+                print("first differing output index:", tfirst, "components (c*n+age):", np.unique(np.nonzero(d[:, tfirst, :])[1])[:44])
+                ch = np.nonzero(d[:, tfirst, :])[0][0]
+                n = x.shape[2] // 11
+                for c in range(11):
+                    dd = d[:, tfirst, c * n:(c + 1) * n]
+                    print("  comp", c, "differing", int(dd.sum()), "of", dd.size, "n_accept", outs[0]["n_accept"][:4])
+                print("chain", ch, "values", x[ch, tfirst, d[ch, tfirst]][:6], y[ch, tfirst, d[ch, tfirst]][:6])
     if a.fuzz:
         st = np.concatenate([outs[0][k] for k in outs[0].files if k.endswith("_status")])
         print(f"fuzz seed {a.fuzz}: {a.fuzz_cases} problem variants, {st.size} chains, status counts {np.bincount(st, minlength=4).tolist()}, "
