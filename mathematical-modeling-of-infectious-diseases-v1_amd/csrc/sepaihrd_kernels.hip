@@ -66,7 +66,7 @@ namespace {
 // ----------------------------------------------------------------------------------
 #if SEPAIHRD_ARITH_FMA
 // tolerance mode folds per-chain constants once per evaluation instead of once per RHS call:
-//   MF_H_INFEC := h_infec / N, the contact row := a_i M(i, .), MF_R_I := gamma_I + h + d_community,
+//   the contact row := (a_i M(i, j)) (h_infec_j / N_j) (MF_H_INFEC := h_infec / N is only its ingredient), MF_R_I := gamma_I + h + d_community,
 //   MF_R_H := gamma_H + d_H + icu, MF_R_ICU := gamma_ICU + d_ICU  (8 instructions fewer per call)
 //   MF_PG := p gamma_p, MF_PI := gamma_p - p gamma_p.
 // The derivatives are written with explicit fma() in ONE fixed association, the one the 16-lane small-batch form
@@ -94,7 +94,7 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     const double S = x[0], E = x[1], P = x[2], A = x[3], I = x[4], H = x[5], ICU = x[6];
 #if SEPAIHRD_ARITH_FMA
     const double total_inf = fma(q.get(MF_THETA), I, P + A);
-    const double inf_pressure = total_inf * q.get(MF_H_INFEC);  // h_infec / N folded
+    const double inf_pressure = total_inf;  // h_infec_j / N_j rides in the contact row (column j) since round 2
 #else
     const double total_inf = P + A + q.get(MF_THETA) * I;
     const double inf_pressure = total_inf * q.get(MF_H_INFEC) * q.get(MF_INV_N);
@@ -431,8 +431,11 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     q.set(MF_R_ICU, q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU));
     q.set(MF_PG, q.get(MF_P) * q.get(MF_GAMMA_P));
     q.set(MF_PI, q.get(MF_GAMMA_P) - q.get(MF_PG));
-    SEP_UNROLL
-    for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, q.get(MF_A) * pb.Mrow[age * LPC + j]);
+    // column j of the contact row also carries age class j's h_infec / N: (a_i M(i,j)) * c_j, so that the pressure
+    // P + A + theta I needs no scaling of its own in the RHS (one multiplication fewer per call, in every form)
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+        ((q.set(MF_MROW0 + J, q.get(MF_A) * pb.Mrow[age * LPC + J] * group_bcast<LPC, J>(q.get(MF_H_INFEC)))), ...);
+    }(std::make_integer_sequence<int, LPC>{});
 #else
     SEP_UNROLL
     for (int j = 0; j < LPC; ++j) q.set(MF_MROW0 + j, pb.Mrow[age * LPC + j]);
@@ -636,6 +639,9 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
                 sch.lo = (c_hi > 0) ? sch.me[c_hi - 1] : -INFINITY;
                 sch.hi = (c_hi < pb.nm) ? sch.me[c_hi] : INFINITY;
                 sch.bk = v_hi;
+                // every LDS read of this (rare) path is complete before it rejoins: the stage code then carries no
+                // s_waitcnt of its own (six per attempt otherwise, one per stage's beta*kappa)
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             } else {
                 SEP_UNROLL
                 for (int s = 0; s < 7; ++s) bks[s] = sch.bk;
@@ -748,10 +754,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         const bool need_inc = active && !reject && (err < 0.5) && grow_relevant;
         double cur_after = cur;
         if (__ballot(need_dec || need_inc) != 0ull) {
-            const double arg = need_dec ? err : fmax(1.0 / 3125.0, err);  // std::pow(5.0, -5.0) == 1/3125
+            const double arg = max_moved_uniform(err, 1.0 / 3125.0);  // 5^-5: the floor of the increase rule; a rejected step has err > 1
             const double expo = need_dec ? -1.0 / (4 - 1) : -1.0 / 5;
             const double pw = 9.0 / 10.0 * pow_ctl(arg, expo);
-            const double f = need_dec ? fmax(pw, 1.0 / 5.0) : pw;
+            const double f = fmax(pw, 1.0 / 5.0);  // the floor of the decrease rule; an increase has pw > 1 (err < 0.5)
             if (need_dec || need_inc) cur_after = cur * f;
         }
 

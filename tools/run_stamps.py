@@ -11,11 +11,13 @@ arith = sys.argv[1] if len(sys.argv) > 1 else "strict"
 hipabi._lib = hipabi.load_library(os.path.join(ROOT, "tools", "libsepaihrd_stamps.so"))
 pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", "synth_400d_n4.json"))
 pb.arith = mm.ARITH_FMA if arith == "fma" else mm.ARITH_STRICT
-theta = draws.jitter_draws(pb, 1, 4096)
+n_chains = int(os.environ.get("STAMP_CHAINS", "4096"))
+pb.solver = int(os.environ.get("STAMP_SOLVER", "0"))
+theta = draws.jitter_draws(pb, 1, n_chains)
 hip = mm.HipObjective(pb)
 hip.eval_batch(theta)
 r = hip.eval_batch(theta)
-quad = os.environ.get("SEPAIHRD_LANE_SPLIT", "") != "0"  # 4096 chains: the 16-lane form unless switched off
+quad = os.environ.get("SEPAIHRD_LANE_SPLIT", "") != "0" and n_chains <= 4096  # the 16-lane form unless switched off
 if quad:
     parts = r["ll_parts"].reshape(-1, 4, 3)   # per wave: 4 chains
     head, body, err = parts[:, 0, 0], parts[:, 0, 1], parts[:, 0, 2]
@@ -27,7 +29,7 @@ else:
     tail, att, errA = parts[:, 1, 0], parts[:, 1, 1], parts[:, 1, 2]
     tailA = parts[:, 2, 0]
 tot = head + body + err + tail
-print("arith", arith, "waves", len(tot), "attempts/wave mean %.1f" % att.mean())
+print("arith", arith, "chains", n_chains, "waves", len(tot), "attempts/wave mean %.1f" % att.mean())
 for name, v in (("head(stage times, schedule)", head), ("RK body (6 RHS + stage sums + xerr)", body),
                 ("error norm + controller", err), ("accept/observe/likelihood tail", tail)):
     print("%-40s %8.0f cycles/attempt  %5.1f %%" % (name, (v / att).mean(), 100 * v.sum() / tot.sum()))
