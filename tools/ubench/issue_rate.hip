@@ -5,7 +5,7 @@
 #include <cstdio>
 
 #define REP8(x) x x x x x x x x
-enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_FMA64_SGPR, OP_FMA32, OP_MOV32, OP_MIX, OP_MAX64, OP_DPP_MOV, OP_FMA64_DEP1, OP_FMA64_DEP2, OP_FMA64_DEP3, OP_FMAC_DPP64 };
+enum { OP_FMA64, OP_MUL64, OP_ADD64, OP_FMA64_SGPR, OP_FMA32, OP_MOV32, OP_MIX, OP_MAX64, OP_DPP_MOV, OP_FMA64_DEP1, OP_FMA64_DEP2, OP_FMA64_DEP3, OP_FMAC_DPP64, OP_PK_FMA32, OP_FMA32_DEP1, OP_MIX32, OP_FMA64_REGS };
 
 template <int OP>
 __global__ void k(double* out, int iters, long long* ticks) {
@@ -14,6 +14,8 @@ __global__ void k(double* out, int iters, long long* ticks) {
     double a0 = 1.0 + lane, a1 = 2.0 + lane, a2 = 3.0 + lane, a3 = 4.0 + lane;
     double a4 = 5.0 + lane, a5 = 6.0 + lane, a6 = 7.0 + lane, a7 = 8.0 + lane;
     double m = 0.999999 + 1e-12 * lane, c = 1e-9 + 1e-15 * lane;
+    double b0 = m, b1 = m + 1e-13, b2 = m + 2e-13, b3 = m + 3e-13, b4 = c, b5 = c * 1.5, b6 = c * 2.5, b7 = c * 3.5;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
     float f0 = lane, f1 = lane + 1, f2 = lane + 2, f3 = lane + 3, f4 = lane + 4, f5 = lane + 5, f6 = lane + 6, f7 = lane + 7;
     float fm = 0.9999f + 1e-6f * lane, fc = 1e-5f * lane;
     for (int i = 0; i < iters; ++i) {
@@ -68,6 +70,24 @@ __global__ void k(double* out, int iters, long long* ticks) {
 #define F(a) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "v"(c));
             F(a0) F(a1) F(a2) F(a3) F(a4) F(a5) F(a6) F(a7)
 #undef F
+        } else if (OP == OP_PK_FMA32) {  // two FP32 FMAs per lane and instruction: twice the flops per issue slot?
+#define F(a) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
+            F(a0) F(a1) F(a2) F(a3) F(a4) F(a5) F(a6) F(a7)
+#undef F
+        } else if (OP == OP_FMA32_DEP1) {
+#define F(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(fm), "v"(fc));
+            F(f0) F(f0) F(f0) F(f0) F(f0) F(f0) F(f0) F(f0)
+#undef F
+        } else if (OP == OP_MIX32) {  // FP32 fma interleaved with FP64 fma (the fp32 arm's inline likelihood)
+#define F(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(fm), "v"(fc));
+#define G(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
+            F(f0) F(f1) F(f2) G(a0) F(f3) F(f4) F(f5) G(a1)
+#undef F
+#undef G
+        } else if (OP == OP_FMA64_REGS) {  // three DIFFERENT register pairs per fma, sixteen source pairs in rotation
+#define F(a, b, cc) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(cc));
+            F(a0, b0, b5) F(a1, b1, b6) F(a2, b2, b7) F(a3, b3, b4) F(a4, b4, b1) F(a5, b5, b2) F(a6, b6, b3) F(a7, b7, b0)
+#undef F
         } else if (OP == OP_MIX) {
             // alternate FP64 fma and 32-bit moves: does a 32-bit op hide behind an FP64 op?
 #define F(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(m), "v"(c));
@@ -107,5 +127,7 @@ int main() {
     run<OP_DPP_MOV>("mov32_dpp", out); run<OP_MIX>("fma64+mov32", out);
     run<OP_FMA64_DEP1>("fma64_dep1", out); run<OP_FMA64_DEP2>("fma64_dep2", out); run<OP_FMA64_DEP3>("fma64_dep3", out);
     run<OP_FMAC_DPP64>("fmac64_dpp", out);
+    run<OP_PK_FMA32>("pk_fma32", out); run<OP_FMA32_DEP1>("fma32_dep1", out); run<OP_MIX32>("3fma32+fma64", out);
+    run<OP_FMA64_REGS>("fma64_regs", out);
     return 0;
 }
