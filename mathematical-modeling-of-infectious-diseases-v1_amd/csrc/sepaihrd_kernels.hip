@@ -854,7 +854,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 // ascending order (the reference's inner loop, SEPAIHRDObjectiveFunction.cpp:264-276).
 // ----------------------------------------------------------------------------------
 constexpr int LL_DAYS_PER_BLOCK = 4;  // one wave per day: fewer, larger workgroups for the dispatcher
-constexpr int LL_SERIAL_MIN_WAVES = 768;  // (chain, stream) lanes needed before the serial walk fills the chip
+// (chain, stream) waves from which the serial walk beats the (chain, day, age)-parallel kernel + its rows[] round trip:
+// measured (Dopri5, tolerance build) 16 384 chains 0.32 vs 0.22 ms, 32 768 chains 0.43 vs 0.45, 65 536 0.75 vs 0.85,
+// 131 072 1.11 vs 1.66 -- the walk wants at least 1.5 waves on every SIMD
+constexpr int LL_SERIAL_MIN_WAVES = 1536;
 template <int LPC>
 __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_kernel(const DevProblem pb, const int B,
                                                                                     const EvalOutputs out,
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
 // Likelihood pass for saturating batches: one lane per (chain, stream) walks the days and, within a day, the
 // ages -- the reference's two nested serial sums -- so there is no cross-lane traffic and no rows[] round trip;
 // the increments of all ages of a chain arrive in one vector load, the observations are wave-uniform
-// (scalar loads).  Needs >= 768 waves of chains to fill the chip (below that the (chain, day, age)-parallel
+// (scalar loads).  Needs >= 1536 waves of (chain, stream) lanes to pay (below that the (chain, day, age)-parallel
 // kernel above is faster); same operations in the same order, so the same bits.  The stream's sum goes to
 // rows[0][stream][chain] and the reduce kernel finishes with n_rows = 1.
 template <int LPC>
@@ -1032,6 +1035,16 @@ inline bool lane_split_wanted(int B) {
 #include "sepaihrd_wave_chain.inc"  // one wavefront per chain: the latency form for batches of up to WAVE_CHAIN_MAX chains
 #endif
 
+// SEPAIHRD_LL_SERIAL_MIN_WAVES=n overrides the batch size from which the separate likelihood pass walks the days in one
+// lane per (chain, stream) (measurement switch; both forms give the same bits)
+inline int ll_serial_min_waves() {
+    static const int v = [] {
+        const char* e = getenv("SEPAIHRD_LL_SERIAL_MIN_WAVES");
+        return e == nullptr ? LL_SERIAL_MIN_WAVES : atoi(e);
+    }();
+    return v;
+}
+
 // ----------------------------------------------------------------------------------
 // launch plumbing
 // ----------------------------------------------------------------------------------
@@ -1047,7 +1060,7 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
                        st, pb, d_theta, B, out, cum_chains);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
-        if ((B + WAVE - 1) / WAVE >= LL_SERIAL_MIN_WAVES / 3) {
+        if ((B + WAVE - 1) / WAVE >= ll_serial_min_waves() / 3) {
             hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC>), dim3((B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out,
                                cum_chains);
             hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains, 1);
