@@ -47,6 +47,10 @@ struct sepaihrd_ctx {
     int32_t* d_nacc = nullptr;
     int32_t* d_nrej = nullptr;
     double* d_parts = nullptr;
+    // d_loglik .. d_parts are views into ONE allocation (results slab: [loglik B][parts 3B][status B][accepted B][rejected B]),
+    // fetched with one copy into a page-locked mirror of the same layout
+    void* d_results = nullptr;
+    void* h_results = nullptr;
     double* d_traj = nullptr;
     size_t cap_traj_elems = 0;
     // likelihood-pass workspace (device), sized for ws_chains chains
@@ -174,13 +178,63 @@ void fence_after(sepaihrd_ctx* c, hipStream_t st) {
 }
 
 void free_staging(sepaihrd_ctx* c) {
-    void* ptrs[] = {c->d_theta, c->d_loglik, c->d_status, c->d_nacc, c->d_nrej, c->d_parts, c->d_traj};
+    void* ptrs[] = {c->d_theta, c->d_results, c->d_traj};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_results) (void)hipHostFree(c->h_results);
     c->d_theta = c->d_loglik = c->d_parts = c->d_traj = nullptr;
     c->d_status = c->d_nacc = c->d_nrej = nullptr;
+    c->d_results = c->h_results = nullptr;
     c->cap_B = 0;
     c->cap_traj_elems = 0;
+}
+
+constexpr size_t RESULT_BYTES_PER_CHAIN = 4 * sizeof(double) + 3 * sizeof(int32_t);
+
+// Staging of the host-pointer entry points for B chains (keeps a trajectory buffer that is already there).  The result
+// views are laid out for THIS batch at the front of the slab, so that one copy fetches them whatever the capacity.
+int ensure_staging(sepaihrd_ctx* ctx, size_t B) {
+    if (B > ctx->cap_B) {
+        const size_t keep_traj = ctx->cap_traj_elems;
+        double* keep = ctx->d_traj;
+        ctx->d_traj = nullptr;
+        free_staging(ctx);
+        ctx->d_traj = keep;
+        ctx->cap_traj_elems = keep_traj;
+        HIP_TRY(hipMalloc((void**)&ctx->d_theta, B * ctx->P * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMalloc(&ctx->d_results, B * RESULT_BYTES_PER_CHAIN), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipHostMalloc(&ctx->h_results, B * RESULT_BYTES_PER_CHAIN, hipHostMallocDefault), ctx, return SEPAIHRD_E_HIP);
+        ctx->cap_B = B;
+    }
+    ctx->d_loglik = static_cast<double*>(ctx->d_results);
+    ctx->d_parts = ctx->d_loglik + B;
+    ctx->d_status = reinterpret_cast<int32_t*>(ctx->d_parts + 3 * B);
+    ctx->d_nacc = ctx->d_status + B;
+    ctx->d_nrej = ctx->d_nacc + B;
+    return SEPAIHRD_OK;
+}
+
+// One copy of the batch's results (the span up to the last array asked for) and the wait; then the caller's arrays are
+// filled from the page-locked mirror.
+int fetch_results(sepaihrd_ctx* ctx, hipStream_t st, int B, double* loglik, int32_t* status, int32_t* n_accept, int32_t* n_reject,
+                  double* ll_parts) {
+    const size_t n = (size_t)B;
+    char* const h = static_cast<char*>(ctx->h_results);
+    const size_t off_parts = n * sizeof(double), off_status = 4 * n * sizeof(double);
+    const size_t off_nacc = off_status + n * sizeof(int32_t), off_nrej = off_nacc + n * sizeof(int32_t);
+    size_t hi = n * sizeof(double);  // the log-likelihoods, always
+    if (ll_parts) hi = off_status;
+    if (status) hi = off_nacc;
+    if (n_accept) hi = off_nrej;
+    if (n_reject) hi = off_nrej + n * sizeof(int32_t);
+    HIP_TRY(hipMemcpyAsync(h, ctx->d_results, hi, hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(st), ctx, return SEPAIHRD_E_HIP);
+    if (loglik) std::memcpy(loglik, h, n * sizeof(double));
+    if (ll_parts) std::memcpy(ll_parts, h + off_parts, n * 3 * sizeof(double));
+    if (status) std::memcpy(status, h + off_status, n * sizeof(int32_t));
+    if (n_accept) std::memcpy(n_accept, h + off_nacc, n * sizeof(int32_t));
+    if (n_reject) std::memcpy(n_reject, h + off_nrej, n * sizeof(int32_t));
+    return SEPAIHRD_OK;
 }
 
 }  // namespace
@@ -562,20 +616,9 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     const size_t traj_elems = traj ? (size_t)B * ctx->T * NUM_COMP * ctx->n : 0;
     if (ctx->pending_B > 0) { ctx->last_error = "eval_batch: a sepaihrd_eval_batch_begin is pending"; return SEPAIHRD_E_INVALID_ARG; }
-    if ((size_t)B > ctx->cap_B) {
-        const size_t keep_traj = ctx->cap_traj_elems;
-        double* keep = ctx->d_traj;
-        ctx->d_traj = nullptr;
-        free_staging(ctx);
-        ctx->d_traj = keep;
-        ctx->cap_traj_elems = keep_traj;
-        HIP_TRY(hipMalloc((void**)&ctx->d_theta, (size_t)B * ctx->P * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_loglik, (size_t)B * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_status, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_nacc, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_nrej, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_parts, (size_t)B * 3 * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        ctx->cap_B = (size_t)B;
+    {
+        const int rc = ensure_staging(ctx, (size_t)B);
+        if (rc != SEPAIHRD_OK) return rc;
     }
     if (traj_elems > ctx->cap_traj_elems) {
         if (ctx->d_traj) (void)hipFree(ctx->d_traj);
@@ -590,20 +633,10 @@ int sepaihrd_eval_batch(sepaihrd_ctx* ctx, const double* theta, int B, double* l
                                               ctx->d_nrej, ctx->d_parts, traj ? ctx->d_traj : nullptr, nullptr);
     if (rc != SEPAIHRD_OK) return rc;
     HIP_TRY(hipDeviceSynchronize(), ctx, return SEPAIHRD_E_HIP);
-    HIP_TRY(hipMemcpy(loglik, ctx->d_loglik, (size_t)B * sizeof(double), hipMemcpyDeviceToHost), ctx,
-            return SEPAIHRD_E_HIP);
-    if (status)
-        HIP_TRY(hipMemcpy(status, ctx->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
-                return SEPAIHRD_E_HIP);
-    if (n_accept)
-        HIP_TRY(hipMemcpy(n_accept, ctx->d_nacc, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
-                return SEPAIHRD_E_HIP);
-    if (n_reject)
-        HIP_TRY(hipMemcpy(n_reject, ctx->d_nrej, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost), ctx,
-                return SEPAIHRD_E_HIP);
-    if (ll_parts)
-        HIP_TRY(hipMemcpy(ll_parts, ctx->d_parts, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost), ctx,
-                return SEPAIHRD_E_HIP);
+    {
+        const int rcf = fetch_results(ctx, nullptr, B, loglik, status, n_accept, n_reject, ll_parts);
+        if (rcf != SEPAIHRD_OK) return rcf;
+    }
     if (traj)
         HIP_TRY(hipMemcpy(traj, ctx->d_traj, traj_elems * sizeof(double), hipMemcpyDeviceToHost), ctx,
                 return SEPAIHRD_E_HIP);
@@ -618,20 +651,9 @@ int sepaihrd_eval_batch_begin(sepaihrd_ctx* ctx, const double* theta, int B) {
     if (ctx->pending_B > 0) { ctx->last_error = "eval_batch_begin: the previous begin has no end yet"; return SEPAIHRD_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     if (!ctx->own_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), ctx, return SEPAIHRD_E_HIP);
-    if ((size_t)B > ctx->cap_B) {
-        const size_t keep_traj = ctx->cap_traj_elems;
-        double* keep = ctx->d_traj;
-        ctx->d_traj = nullptr;
-        free_staging(ctx);
-        ctx->d_traj = keep;
-        ctx->cap_traj_elems = keep_traj;
-        HIP_TRY(hipMalloc((void**)&ctx->d_theta, (size_t)B * ctx->P * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_loglik, (size_t)B * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_status, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_nacc, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_nrej, (size_t)B * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMalloc((void**)&ctx->d_parts, (size_t)B * 3 * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
-        ctx->cap_B = (size_t)B;
+    {
+        const int rc = ensure_staging(ctx, (size_t)B);
+        if (rc != SEPAIHRD_OK) return rc;
     }
     if (sepaihrd_reserve(ctx, B) != SEPAIHRD_OK) return SEPAIHRD_E_HIP;  // workspace growth is not stream-ordered
     HIP_TRY(hipMemcpyAsync(ctx->d_theta, theta, (size_t)B * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->own_stream), ctx,
@@ -650,14 +672,7 @@ int sepaihrd_eval_batch_end(sepaihrd_ctx* ctx, double* loglik, int32_t* status, 
     if (B <= 0) { ctx->last_error = "eval_batch_end: nothing pending"; return SEPAIHRD_E_INVALID_ARG; }
     ctx->pending_B = 0;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    hipStream_t st = ctx->own_stream;
-    if (loglik) HIP_TRY(hipMemcpyAsync(loglik, ctx->d_loglik, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
-    if (status) HIP_TRY(hipMemcpyAsync(status, ctx->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
-    if (n_accept) HIP_TRY(hipMemcpyAsync(n_accept, ctx->d_nacc, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
-    if (n_reject) HIP_TRY(hipMemcpyAsync(n_reject, ctx->d_nrej, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
-    if (ll_parts) HIP_TRY(hipMemcpyAsync(ll_parts, ctx->d_parts, (size_t)B * 3 * sizeof(double), hipMemcpyDeviceToHost, st), ctx, return SEPAIHRD_E_HIP);
-    HIP_TRY(hipStreamSynchronize(st), ctx, return SEPAIHRD_E_HIP);
-    return SEPAIHRD_OK;
+    return fetch_results(ctx, ctx->own_stream, B, loglik, status, n_accept, n_reject, ll_parts);
 }
 
 int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
