@@ -887,6 +887,7 @@ struct sepaihrd_mh {
     double* h_stage[2] = {nullptr, nullptr};  // pinned [C][P] each: the caller fills one while the other's copy may still run
     int stage_turn = 0;
     uint8_t* h_pack = nullptr;   // pinned
+    void* h_fetch = nullptr;     // pinned mirror of [loglik C][status C] (one allocation on the device too: one copy per fetch)
     uint8_t* d_pack = nullptr;
     size_t pack_bytes = 0, off_scale = 0, off_chain = 0, off_rows = 0;
     // rank-one covariance updates not yet applied (see mh_rank1_catchup_cov_kernel): consecutive history rows from
@@ -941,17 +942,24 @@ int mh_adapt_step(sepaihrd_mh* mh, double gamma, int adapt) {
     return rc;
 }
 
+// log-likelihoods (and statuses) of the last evaluation: one copy into the page-locked mirror, the wait, two memcpy
+int mh_fetch_values(sepaihrd_mh* mh, double* loglik, int32_t* status) {
+    sepaihrd_ctx* ctx = mh->ctx;
+    const size_t C = (size_t)mh->st.C;
+    const size_t bytes = C * sizeof(double) + (status ? C * sizeof(int32_t) : 0);
+    HIP_TRY(hipMemcpyAsync(mh->h_fetch, mh->d_loglik, bytes, hipMemcpyDeviceToHost, mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    std::memcpy(loglik, mh->h_fetch, C * sizeof(double));
+    if (status) std::memcpy(status, static_cast<char*>(mh->h_fetch) + C * sizeof(double), C * sizeof(int32_t));
+    return SEPAIHRD_OK;
+}
+
 int mh_eval(sepaihrd_mh* mh, const double* d_theta, double* loglik, int32_t* status) {
     sepaihrd_ctx* ctx = mh->ctx;
     const int C = mh->st.C;
     const int rc = sepaihrd_eval_batch_device(ctx, d_theta, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, mh->stream);
     if (rc != SEPAIHRD_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, mh->stream), ctx, return SEPAIHRD_E_HIP);
-    if (status)
-        HIP_TRY(hipMemcpyAsync(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost, mh->stream), ctx,
-                return SEPAIHRD_E_HIP);
-    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
-    return SEPAIHRD_OK;
+    return mh_fetch_values(mh, loglik, status);
 }
 }  // namespace
 
@@ -999,8 +1007,8 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     dalloc((void**)&st.hist, CP * (size_t)capacity * sizeof(double));
     dalloc((void**)&mh->d_z, CP * sizeof(double));
     dalloc((void**)&mh->d_scale, (size_t)C * sizeof(double));
-    dalloc((void**)&mh->d_loglik, (size_t)C * sizeof(double));
-    dalloc((void**)&mh->d_status, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&mh->d_loglik, (size_t)C * (sizeof(double) + sizeof(int32_t)));
+    mh->d_status = mh->d_loglik ? reinterpret_cast<int32_t*>(mh->d_loglik + C) : nullptr;
     dalloc((void**)&mh->d_accept, (size_t)C);
     dalloc((void**)&mh->d_z_stage, CP * sizeof(double));
     {
@@ -1011,6 +1019,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         mh->pack_bytes = mh->off_rows + CP * sizeof(double);
         dalloc((void**)&mh->d_pack, mh->pack_bytes);
         if (ok && hipHostMalloc((void**)&mh->h_pack, mh->pack_bytes, hipHostMallocDefault) != hipSuccess) { mh->h_pack = nullptr; ok = false; }
+        if (ok && hipHostMalloc(&mh->h_fetch, (size_t)C * (sizeof(double) + sizeof(int32_t)), hipHostMallocDefault) != hipSuccess) { mh->h_fetch = nullptr; ok = false; }
         for (int b = 0; b < 2; ++b)
             if (ok && hipHostMalloc((void**)&mh->h_stage[b], CP * sizeof(double), hipHostMallocDefault) != hipSuccess) { mh->h_stage[b] = nullptr; ok = false; }
     }
@@ -1033,6 +1042,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         ctx->last_error = "mh_create: device allocation or initialisation failed (history = C * capacity * P doubles)";
         for (void* p : mh->allocs) (void)hipFree(p);
         if (mh->h_pack) (void)hipHostFree(mh->h_pack);
+        if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
         for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
         if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
         if (mh->copy_stream) (void)hipStreamDestroy(mh->copy_stream);
@@ -1051,6 +1061,7 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
     if (mh->h_pack) (void)hipHostFree(mh->h_pack);
+    if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
     for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
     for (void* p : mh->allocs) (void)hipFree(p);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
@@ -1144,13 +1155,7 @@ int sepaihrd_mh_fetch(sepaihrd_mh* mh, double* loglik, int32_t* status) {
     if (!mh || !loglik) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    const int C = mh->st.C;
-    HIP_TRY(hipMemcpyAsync(loglik, mh->d_loglik, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, mh->stream), ctx, return SEPAIHRD_E_HIP);
-    if (status)
-        HIP_TRY(hipMemcpyAsync(status, mh->d_status, (size_t)C * sizeof(int32_t), hipMemcpyDeviceToHost, mh->stream), ctx,
-                return SEPAIHRD_E_HIP);
-    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
-    return SEPAIHRD_OK;
+    return mh_fetch_values(mh, loglik, status);
 }
 
 int sepaihrd_mh_commit(sepaihrd_mh* mh, const uint8_t* accept) {
