@@ -248,6 +248,9 @@ public:
                                                                 IParameterManager& parameterManager);
     void setHostThreads(int n) { host_threads_ = n; }  // per-run cap on the OpenMP team (0 = the CPU share)
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
+    // wall time of the iteration loop of the last device-resident run (proposal 1 staged .. last accept test), without
+    // the set-up before it (history allocation, initial values) and the read-back after it; groups: the slowest group
+    double lastLoopSeconds() const { return last_loop_seconds_; }
 private:
     struct Chain;
     using BatchEval = std::function<void(const double*, int, double*)>;
@@ -260,6 +263,7 @@ private:
     std::vector<std::vector<unsigned char>> traces_;
     std::vector<double> initial_cov_;  // row-major P x P, empty = none
     int host_threads_ = 0;
+    double last_loop_seconds_ = 0.0;
 };
 
 }  // namespace epidemic

@@ -462,6 +462,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         if (t % adaptation_period_ != 0) return 1;
         return static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 3 : 2;
     };
+    const auto loop_begin = now();
     if (iterations_ > 1) {  // proposal 1: nothing to commit yet
         check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
         z_next = sepaihrd_mh_staging_buffer(mh);
@@ -579,6 +580,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 if (needs_patch[static_cast<size_t>(c)]) { if (alt_ready[static_cast<size_t>(c)]) ++alt_used; else ++alt_missing; }
             }
     }
+    last_loop_seconds_ = secs(loop_begin, now());
     {   // the best states were kept on the device
         std::vector<double> best_all(CP);
         check(sepaihrd_mh_read_best(mh, best_all.data()), "mh_read_best");
@@ -637,6 +639,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
     std::vector<std::vector<OptimizationResult>> parts(static_cast<size_t>(G));
     std::vector<std::vector<std::vector<unsigned char>>> part_traces(static_cast<size_t>(G));
     std::vector<std::string> errors(static_cast<size_t>(G));
+    std::vector<double> loop_secs(static_cast<size_t>(G), 0.0);
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g) {
         workers.emplace_back([&, g]() {
@@ -648,6 +651,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
                 const std::vector<double> init(initial.begin() + static_cast<size_t>(c0) * P, initial.begin() + static_cast<size_t>(c1) * P);
                 parts[static_cast<size_t>(g)] = local.optimizeChainsOnDevice(init, c1 - c0, *objectives[static_cast<size_t>(g)], pm);
                 part_traces[static_cast<size_t>(g)] = local.traces_;
+                loop_secs[static_cast<size_t>(g)] = local.last_loop_seconds_;
             } catch (const std::exception& e) { errors[static_cast<size_t>(g)] = e.what(); }
         });
     }
@@ -656,6 +660,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
         if (!e.empty()) throw ModelException("MetropolisHastingsSampler", e);
     std::vector<OptimizationResult> results;
     traces_.clear();
+    last_loop_seconds_ = *std::max_element(loop_secs.begin(), loop_secs.end());
     for (int g = 0; g < G; ++g) {
         for (OptimizationResult& r : parts[static_cast<size_t>(g)]) results.push_back(std::move(r));
         for (auto& t : part_traces[static_cast<size_t>(g)]) traces_.push_back(std::move(t));

@@ -37,11 +37,14 @@ Eigen::VectorXd vec(const double* p, int n) {
     return v;
 }
 thread_local std::string g_error;
+thread_local double g_last_mh_loop_seconds = 0.0;
 }  // namespace
 
 extern "C" {
 
 const char* host_last_error(void) { return g_error.c_str(); }
+// iteration loop of this thread's last device-resident sampler run, without set-up and read-back (seconds)
+double host_last_mh_loop_seconds(void) { return g_last_mh_loop_seconds; }
 
 // names / npi_names: '\n'-joined; sigmas: [P].  Bounds come from pb->lower/upper.
 // with_objective = 0 builds the parameter manager only (no device needed)
@@ -249,6 +252,7 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
             const std::vector<double> init(initial, initial + static_cast<size_t>(C) * P);
             res = use_scalar_interface == 2 ? mh.optimizeChainsOnDevice(init, C, *h->obj, *h->pm)  // device-resident state
                                             : mh.optimizeChains(init, C, *h->obj, *h->pm);
+            g_last_mh_loop_seconds = mh.lastLoopSeconds();
             if (accept_trace)
                 for (int c = 0; c < C; ++c)
                     std::copy(mh.acceptTraces()[static_cast<size_t>(c)].begin(), mh.acceptTraces()[static_cast<size_t>(c)].end(),
@@ -508,6 +512,7 @@ int host_mh_run_groups(void** handles, int G, int C, const double* initial, uint
         mh.setSeed(seed);
         const std::vector<OptimizationResult> res =
             mh.optimizeChainGroupsOnDevice(std::vector<double>(initial, initial + static_cast<size_t>(C) * P), C, objs, *h0->pm);
+        g_last_mh_loop_seconds = mh.lastLoopSeconds();
         for (int c = 0; c < C; ++c) {
             const OptimizationResult& r = res[static_cast<size_t>(c)];
             if (accepted) accepted[c] = static_cast<int32_t>(r.additionalStats.at("accepted_count"));

@@ -28,6 +28,7 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.host_last_error.restype = C.c_char_p
+    lib.host_last_mh_loop_seconds.restype = C.c_double
     lib.host_objective_create.restype = vp
     lib.host_objective_create.argtypes = [C.POINTER(hipabi.sepaihrd_problem), C.c_char_p, C.c_char_p, vp, C.c_int,
                                           C.c_int, C.c_int]
@@ -283,7 +284,8 @@ class HostObjective:
             raise RuntimeError(self.lib.host_last_error().decode())
         assert ns.value == n_s
         return {"accepted": accepted, "best_value": best_value, "best": best, "final_scale": final_scale,
-                "accept_trace": trace[:, :iterations - 1], "samples": samples, "sample_values": values}
+                "accept_trace": trace[:, :iterations - 1], "samples": samples, "sample_values": values,
+                "loop_seconds": float(self.lib.host_last_mh_loop_seconds())}
 
 
 def metropolis_hastings_groups(objectives, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
@@ -303,7 +305,8 @@ def metropolis_hastings_groups(objectives, initial, seed: int, iterations: int, 
                                 accepted.ctypes.data, best_value.ctypes.data, best.ctypes.data, trace.ctypes.data)
     if rc:
         raise RuntimeError(lib.host_last_error().decode())
-    return {"accepted": accepted, "best_value": best_value, "best": best, "accept_trace": trace[:, :iterations - 1]}
+    return {"accepted": accepted, "best_value": best_value, "best": best, "accept_trace": trace[:, :iterations - 1],
+            "loop_seconds": float(lib.host_last_mh_loop_seconds())}
 
 
 def reference_constructors(pb, thetas) -> dict:
