@@ -89,6 +89,57 @@ inline double canonical53(std::mt19937& g) {
     if (__builtin_expect(ret >= 1.0, 0)) ret = std::nextafter(1.0, 0.0);
     return ret;
 }
+// A chain's random stream as a look-ahead queue of canonical uniforms (generate_canonical<double, 53>: always two
+// 32-bit outputs each).  Both continuations of an accept test read the SAME queue -- the branch that draws the uniform
+// takes element 0 for it and builds its normals from element 1 on, the other branch builds them from element 0 on -- and
+// the test then consumes what the branch taken used.  Nothing is generated twice and no 2.5-KB generator is copied
+// (the device-resident loop copied one per chain and iteration: 10 MB per iteration at 4096 chains).
+struct CanonicalQueue {
+    std::mt19937 gen;
+    std::vector<double> buf;   // [head, tail): generated, not yet consumed
+    size_t head = 0, tail = 0;
+    void ensure(size_t n) {    // at least n unconsumed elements
+        if (tail - head < n) refill(n);
+    }
+    void refill(size_t n) {
+        if (buf.size() < std::max<size_t>(n, 320)) buf.resize(std::max<size_t>(2 * n, 320));  // 62 normals take ~80 elements
+        if (head > 0) {
+            std::memmove(buf.data(), buf.data() + head, (tail - head) * sizeof(double));
+            tail -= head;
+            head = 0;
+        }
+        double* const b = buf.data();
+        const size_t cap = buf.size();
+        while (tail < cap) b[tail++] = canonical53(gen);
+    }
+    double at(size_t i) { ensure(i + 1); return buf[head + i]; }
+    void consume(size_t n) { head += n; }
+};
+// std::normal_distribution<double> (polar method) over the queue from element `from` on; returns the elements it used
+inline size_t standard_normals_from_queue(CanonicalQueue& q, size_t from, double* dst, int P) {
+    size_t pos = from;
+    q.ensure(from + static_cast<size_t>(P) + static_cast<size_t>(P) / 2 + 8);  // the usual need (27 % of the pairs are rejected)
+    const double* b = q.buf.data() + q.head;
+    size_t avail = q.tail - q.head;
+    for (int i = 0; i < P; i += 2) {
+        double x, y, r2;
+        do {
+            if (__builtin_expect(pos + 2 > avail, 0)) {  // a long run of rejections: more of the stream
+                q.ensure(pos + 64);
+                b = q.buf.data() + q.head;
+                avail = q.tail - q.head;
+            }
+            x = 2.0 * b[pos] - 1.0;
+            y = 2.0 * b[pos + 1] - 1.0;
+            pos += 2;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = std::sqrt(-2 * std::log(r2) / r2);
+        dst[i] = (y * mult) * 1.0 + 0.0;
+        if (i + 1 < P) dst[i + 1] = (x * mult) * 1.0 + 0.0;
+    }
+    return pos - from;
+}
 inline void draw_standard_normals(std::mt19937& g, double* dst, int P) {
     for (int i = 0; i < P; i += 2) {
         double x, y, r2;
@@ -380,8 +431,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     // outcome of that test (a generator copy takes the uniform first); chains whose test needs no uniform
     // draw theirs from the untouched stream afterwards.
     struct Light {
-        std::mt19937 gen[2];  // gen[cur]: the chain's stream; gen[1 - cur]: its copy that already drew the uniform
-        int cur = 0;
+        CanonicalQueue rng;   // the chain's stream, with look-ahead
+        size_t used_likely = 0, used_alt = 0;  // queue elements the two continuations of the pending accept test take
         double log_u = 0.0;   // log of the uniform of the branch that draws it
         double lp = 0.0, log_scale = 0.0, scale = 1.0, best = 0.0;
         std::vector<unsigned char> recent;  // ring of the last 1000 accept flags (:107-110) + their sum
@@ -410,7 +461,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     traces_.assign(static_cast<size_t>(C), {});
     std::vector<int32_t> sample_rows;
     if (store_samples_) sample_rows.push_back(0);
-    auto draw_normals = [P](std::mt19937& g, double* dst) { draw_standard_normals(g, dst, P); };  // generateProposal :91-102
+    // generateProposal :91-102 over the chain's queue from element `from` on; returns the elements used
+    auto draw_normals = [P](CanonicalQueue& q, size_t from, double* dst) { return standard_normals_from_queue(q, from, dst, P); };
     // adaptGlobalScale (:104-152) as a function of the accept flag: the new log-scale, without touching the chain.
     // Evaluated twice per chain AHEAD of the accept test (while the device works) so that the exp() of the branch
     // taken is ready, and once more in the test itself for the ring bookkeeping -- same arithmetic both times.
@@ -439,13 +491,13 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int c = 0; c < C; ++c) {
         Light& ch = chains[static_cast<size_t>(c)];
-        ch.gen[0].seed(seed_ + static_cast<uint32_t>(c));
+        ch.rng.gen.seed(seed_ + static_cast<uint32_t>(c));
         ch.lp = ch.best = values[static_cast<size_t>(c)];
         ch.best_x.assign(initial.begin() + static_cast<size_t>(c) * P, initial.begin() + static_cast<size_t>(c + 1) * P);
         ch.recent.assign(1000, 0);
         if (store_samples_) ch.sample_values.push_back(ch.lp);
         traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
-        draw_normals(ch.gen[0], &z_next[static_cast<size_t>(c) * P]);  // proposal 1
+        ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
         scale[static_cast<size_t>(c)] = ch.scale;
     }
 
@@ -477,11 +529,9 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Light& ch = chains[static_cast<size_t>(c)];
-            std::mt19937& with_u = ch.gen[1 - ch.cur];
-            with_u = ch.gen[ch.cur];
-            std::uniform_real_distribution<double> u_dist(0.0, 1.0);
-            ch.log_u = std::log(u_dist(with_u));                                   // :327
-            if (more) draw_normals(with_u, &z_next[static_cast<size_t>(c) * P]);
+            // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
+            ch.log_u = std::log(ch.rng.at(0));                                     // :327
+            ch.used_likely = 1 + (more ? draw_normals(ch.rng, 1, &z_next[static_cast<size_t>(c) * P]) : 0);
             if (adapt_scale_) {
                 bool e;
                 for (int a = 0; a < 2; ++a) {
@@ -508,11 +558,15 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 #else
                 const int tid = 0, nt = 1;
 #endif
-                for (int c = tid; c < C; c += nt) {
-                    if (tid == 0 && (c / nt) % 4 == 0 && !sepaihrd_mh_busy(mh)) stop.store(true, std::memory_order_relaxed);
+                // the same blocks of chains as the loops before and after (schedule(static)): a chain's queue stays in
+                // the cache of the core that fills and consumes it
+                const int blk = (C + nt - 1) / nt;
+                const int c_end = std::min(C, (tid + 1) * blk);
+                for (int c = tid * blk; c < c_end; ++c) {
+                    if (tid == 0 && (c % 4) == 0 && !sepaihrd_mh_busy(mh)) stop.store(true, std::memory_order_relaxed);
                     if (stop.load(std::memory_order_relaxed)) break;
                     Light& ch = chains[static_cast<size_t>(c)];
-                    draw_normals(ch.gen[ch.cur], &z_alt[static_cast<size_t>(c) * P]);
+                    ch.used_alt = draw_normals(ch.rng, 0, &z_alt[static_cast<size_t>(c) * P]);
                     alt_ready[static_cast<size_t>(c)] = 1;
                 }
             }
@@ -532,9 +586,10 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             if (log_ratio >= 0.0) {
                 acc = true;  // no uniform drawn: the next normals come from the untouched stream
                 needs_patch[static_cast<size_t>(c)] = more ? 1 : 0;
-                if (more && !alt_ready[static_cast<size_t>(c)]) draw_normals(ch.gen[ch.cur], &z_alt[static_cast<size_t>(c) * P]);
+                if (more && !alt_ready[static_cast<size_t>(c)]) ch.used_alt = draw_normals(ch.rng, 0, &z_alt[static_cast<size_t>(c) * P]);
+                ch.rng.consume(more ? ch.used_alt : 0);
             } else {
-                ch.cur = 1 - ch.cur;  // the stream that drew the uniform is the real one; its normals are staged
+                ch.rng.consume(ch.used_likely);  // the continuation that drew the uniform is the real one; its normals are staged
                 if (ch.log_u < log_ratio) acc = true;
             }
             accept[static_cast<size_t>(c)] = acc ? 1 : 0;

@@ -23,9 +23,10 @@ def load_library() -> C.CDLL:
     if _lib is not None:
         return _lib
     hipabi.load_library()  # torch-first HIP runtime + libsepaihrd_hip.so, then the host library
-    if not os.path.exists(LIB_PATH):
-        raise FileNotFoundError(f"{LIB_PATH} not found: run __graft_entry__.build()")
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("SEPAIHRD_HOST_LIB") or LIB_PATH  # env override: experiment builds only
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not found: run __graft_entry__.build()")
+    lib = C.CDLL(path)
     vp = C.c_void_p
     lib.host_last_error.restype = C.c_char_p
     lib.host_last_mh_loop_seconds.restype = C.c_double
