@@ -314,6 +314,25 @@ int sepaihrd_mh_stage_normals(sepaihrd_mh *mh, const double *z);
 double *sepaihrd_mh_staging_buffer(sepaihrd_mh *mh);
 int sepaihrd_mh_step(sepaihrd_mh *mh, const uint8_t *accept, const double *scale, const int32_t *patch_chain,
                      const double *patch_z, int n_patch, double gamma, int adapt);
+/* The iteration with the accept test ON THE DEVICE (MetropolisHastingsSampler.cpp:318-331), so that nothing of the host
+ * stands between one evaluation and the next.  While proposal t is being evaluated the caller fills
+ *   test_buffer    page-locked doubles [log_u C][scale_reject C][scale_accept C][z_plain C*P]: the log of the uniform the
+ *                  test would draw (from the chain's stream), the scale of the NEXT proposal for either outcome of the
+ *                  test, and the next proposal's normals for the continuation that draws NO uniform (log_ratio >= 0);
+ *   stage_normals  (as above) the next proposal's normals for the continuation that DOES draw it;
+ * and calls
+ *   step_tested    upload (copy stream, at once) -> [when evaluation t is done] test of every chain against its current
+ *                  value (safeEvaluate's rule for failed / non-finite values, :65-74) -> commit -> adapt -> proposal t + 1
+ *                  with the normals of the continuation taken and the scale selected -> evaluation t + 1.  last != 0:
+ *                  test and commit only.  Returns at once;
+ *   fetch_test     waits for THAT test: the values it compared [C] and flags [C] (bit 0 accepted, bit 1 best value of
+ *                  the chain so far -- the device keeps the best states --, bit 2 no uniform was drawn): the caller's
+ *                  bookkeeping for iteration t then runs while evaluation t + 1 does.  One test in flight at a time.
+ *   set_values     the chains' current values before the first test (the values of x0). */
+int sepaihrd_mh_set_values(sepaihrd_mh *mh, const double *values);
+double *sepaihrd_mh_test_buffer(sepaihrd_mh *mh);
+int sepaihrd_mh_step_tested(sepaihrd_mh *mh, double gamma, int adapt, int last);
+int sepaihrd_mh_fetch_test(sepaihrd_mh *mh, double *values, uint8_t *flags);
 int sepaihrd_mh_commit(sepaihrd_mh *mh, const uint8_t *accept);
 int sepaihrd_mh_adapt(sepaihrd_mh *mh, double gamma, int refresh, int recompute_full);
 int sepaihrd_mh_read_history(sepaihrd_mh *mh, const int32_t *rows, int n_rows, double *out);

@@ -888,6 +888,18 @@ struct sepaihrd_mh {
     int stage_turn = 0;
     uint8_t* h_pack = nullptr;   // pinned
     void* h_fetch = nullptr;     // pinned mirror of [loglik C][status C] (one allocation on the device too: one copy per fetch)
+    // accept test on the device (sepaihrd_mh_step_tested): current and best values per chain, the test's inputs
+    // [log_u C][scale_reject C][scale_accept C][z_plain C*P] (page-locked mirror filled by the caller while the evaluation
+    // runs), its outputs [values C doubles][flags C bytes] with their page-locked mirror, the scale it selected
+    double* d_lp = nullptr;
+    double* d_best_lp = nullptr;
+    double* d_test = nullptr;
+    double* h_test = nullptr;
+    double* d_scale_sel = nullptr;
+    void* d_test_out = nullptr;
+    void* h_test_out = nullptr;
+    hipEvent_t ev_test_up = nullptr, ev_tested = nullptr, ev_fetched = nullptr, ev_proposed = nullptr;
+    bool values_set = false, test_pending = false, proposed_once = false;
     uint8_t* d_pack = nullptr;
     size_t pack_bytes = 0, off_scale = 0, off_chain = 0, off_rows = 0;
     // rank-one covariance updates not yet applied (see mh_rank1_catchup_cov_kernel): consecutive history rows from
@@ -1011,6 +1023,11 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     mh->d_status = mh->d_loglik ? reinterpret_cast<int32_t*>(mh->d_loglik + C) : nullptr;
     dalloc((void**)&mh->d_accept, (size_t)C);
     dalloc((void**)&mh->d_z_stage, CP * sizeof(double));
+    dalloc((void**)&mh->d_lp, (size_t)C * sizeof(double));
+    dalloc((void**)&mh->d_best_lp, (size_t)C * sizeof(double));
+    dalloc((void**)&mh->d_test, (3 * (size_t)C + CP) * sizeof(double));
+    dalloc((void**)&mh->d_scale_sel, (size_t)C * sizeof(double));
+    dalloc(&mh->d_test_out, (size_t)C * (sizeof(double) + 1));
     {
         auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
         mh->off_scale = up8((size_t)C);
@@ -1020,6 +1037,8 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         dalloc((void**)&mh->d_pack, mh->pack_bytes);
         if (ok && hipHostMalloc((void**)&mh->h_pack, mh->pack_bytes, hipHostMallocDefault) != hipSuccess) { mh->h_pack = nullptr; ok = false; }
         if (ok && hipHostMalloc(&mh->h_fetch, (size_t)C * (sizeof(double) + sizeof(int32_t)), hipHostMallocDefault) != hipSuccess) { mh->h_fetch = nullptr; ok = false; }
+        if (ok && hipHostMalloc((void**)&mh->h_test, (3 * (size_t)C + CP) * sizeof(double), hipHostMallocDefault) != hipSuccess) { mh->h_test = nullptr; ok = false; }
+        if (ok && hipHostMalloc(&mh->h_test_out, (size_t)C * (sizeof(double) + 1), hipHostMallocDefault) != hipSuccess) { mh->h_test_out = nullptr; ok = false; }
         for (int b = 0; b < 2; ++b)
             if (ok && hipHostMalloc((void**)&mh->h_stage[b], CP * sizeof(double), hipHostMallocDefault) != hipSuccess) { mh->h_stage[b] = nullptr; ok = false; }
     }
@@ -1027,6 +1046,8 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     if (ok && hipStreamCreateWithFlags(&mh->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     if (ok && hipStreamCreateWithFlags(&mh->copy_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&mh->ev_staged, hipEventDisableTiming) != hipSuccess) ok = false;
+    for (hipEvent_t* e : {&mh->ev_test_up, &mh->ev_tested, &mh->ev_fetched, &mh->ev_proposed})
+        if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok) {
         std::vector<double> cov_all(CPP);
         for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
@@ -1043,8 +1064,11 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         for (void* p : mh->allocs) (void)hipFree(p);
         if (mh->h_pack) (void)hipHostFree(mh->h_pack);
         if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
+        if (mh->h_test) (void)hipHostFree(mh->h_test);
+        if (mh->h_test_out) (void)hipHostFree(mh->h_test_out);
         for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
         if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
+        for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed}) if (e) (void)hipEventDestroy(e);
         if (mh->copy_stream) (void)hipStreamDestroy(mh->copy_stream);
         if (mh->stream) (void)hipStreamDestroy(mh->stream);
         delete mh;
@@ -1060,8 +1084,11 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (mh->copy_stream) { (void)hipStreamSynchronize(mh->copy_stream); (void)hipStreamDestroy(mh->copy_stream); }
     if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
+    for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed}) if (e) (void)hipEventDestroy(e);
     if (mh->h_pack) (void)hipHostFree(mh->h_pack);
     if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
+    if (mh->h_test) (void)hipHostFree(mh->h_test);
+    if (mh->h_test_out) (void)hipHostFree(mh->h_test_out);
     for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
     for (void* p : mh->allocs) (void)hipFree(p);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
@@ -1156,6 +1183,101 @@ int sepaihrd_mh_fetch(sepaihrd_mh* mh, double* loglik, int32_t* status) {
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     return mh_fetch_values(mh, loglik, status);
+}
+
+int sepaihrd_mh_set_values(sepaihrd_mh* mh, const double* values) {
+    if (!mh || !values) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    const size_t bytes = (size_t)mh->st.C * sizeof(double);
+    HIP_TRY(hipMemcpy(mh->d_lp, values, bytes, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(mh->d_best_lp, values, bytes, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    mh->values_set = true;
+    return SEPAIHRD_OK;
+}
+
+double* sepaihrd_mh_test_buffer(sepaihrd_mh* mh) { return mh ? mh->h_test : nullptr; }
+
+int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) {
+    if (!mh || adapt < 0 || adapt > 3) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    const int C = mh->st.C, P = mh->st.P;
+    if (!mh->values_set) { ctx->last_error = "mh_step_tested: call sepaihrd_mh_set_values first"; return SEPAIHRD_E_INVALID_ARG; }
+    if (mh->test_pending) { ctx->last_error = "mh_step_tested: the previous test has not been fetched"; return SEPAIHRD_E_INVALID_ARG; }
+    if (!last && !mh->staged) { ctx->last_error = "mh_step_tested: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
+    if (mh->rows >= mh->st.capacity) { ctx->last_error = "mh_step_tested: history capacity exhausted"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    hipStream_t st = mh->stream, cs = mh->copy_stream;
+    const size_t CP = (size_t)C * P;
+    // the test's inputs travel on the copy stream while the evaluation still runs; they may not overwrite what the
+    // previous proposal is reading
+    if (mh->proposed_once) HIP_TRY(hipStreamWaitEvent(cs, mh->ev_proposed, 0), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(mh->d_test, mh->h_test, (3 * (size_t)C + (last ? 0 : CP)) * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
+            return SEPAIHRD_E_HIP);
+    HIP_TRY(hipEventRecord(mh->ev_test_up, cs), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamWaitEvent(st, mh->ev_test_up, 0), ctx, return SEPAIHRD_E_HIP);
+    double* const d_values = static_cast<double*>(mh->d_test_out);
+    uint8_t* const d_flags = reinterpret_cast<uint8_t*>(d_values + C);
+    if (!last && adapt <= 1) {
+        // no covariance refresh between commit and proposal: test, commit and proposal in one launch
+        HIP_TRY(hipStreamWaitEvent(st, mh->ev_staged, 0), ctx, return SEPAIHRD_E_HIP);  // the staged normals have landed
+        if (sampler_test_commit_propose(mh->st, ctx->dp, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C,
+                                        mh->d_lp, mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, mh->d_z_stage,
+                                        mh->d_test + 3 * (size_t)C, mh->rows, st) != 0) {
+            ctx->last_error = "mh_step_tested: launch failed";
+            return SEPAIHRD_E_HIP;
+        }
+        HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventRecord(mh->ev_proposed, st), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipStreamWaitEvent(cs, mh->ev_tested, 0), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
+                return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
+        mh->test_pending = true;
+        mh->proposed_once = true;
+        mh->rows++;
+        if (adapt == 1) mh_queue_rank1(mh, gamma);  // as mh_adapt_step: the queued update names history row rows - 1
+        std::swap(mh->d_z, mh->d_z_stage);
+        mh->staged = false;
+        return sepaihrd_eval_batch_device(ctx, mh->st.prop, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, st);
+    }
+    int rc = sampler_accept_test(C, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C, mh->d_lp,
+                                 mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, st);
+    if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);
+    // the outcome goes back on the copy stream as soon as the test has run; the main stream does not wait for it
+    HIP_TRY(hipStreamWaitEvent(cs, mh->ev_tested, 0), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
+            return SEPAIHRD_E_HIP);
+    HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
+    mh->test_pending = true;
+    rc = sampler_commit(mh->st, d_flags, mh->rows, st);
+    if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
+    mh->rows++;
+    if (last) return SEPAIHRD_OK;
+    rc = mh_adapt_step(mh, gamma, adapt);
+    if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipStreamWaitEvent(st, mh->ev_staged, 0), ctx, return SEPAIHRD_E_HIP);  // the staged normals have landed
+    rc = sampler_propose_select(mh->st, ctx->dp, mh->d_z_stage, mh->d_test + 3 * (size_t)C, d_flags, mh->d_scale_sel, st);
+    if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipEventRecord(mh->ev_proposed, st), ctx, return SEPAIHRD_E_HIP);
+    mh->proposed_once = true;
+    std::swap(mh->d_z, mh->d_z_stage);
+    mh->staged = false;
+    return sepaihrd_eval_batch_device(ctx, mh->st.prop, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, st);
+}
+
+int sepaihrd_mh_fetch_test(sepaihrd_mh* mh, double* values, uint8_t* flags) {
+    if (!mh || !values || !flags) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (!mh->test_pending) { ctx->last_error = "mh_fetch_test: no test pending"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipEventSynchronize(mh->ev_fetched), ctx, return SEPAIHRD_E_HIP);
+    const size_t C = (size_t)mh->st.C;
+    std::memcpy(values, mh->h_test_out, C * sizeof(double));
+    std::memcpy(flags, static_cast<const char*>(mh->h_test_out) + C * sizeof(double), C);
+    mh->test_pending = false;
+    return SEPAIHRD_OK;
 }
 
 int sepaihrd_mh_commit(sepaihrd_mh* mh, const uint8_t* accept) {

@@ -172,6 +172,18 @@ struct SamplerState {
 };
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
+// the accept test on the device (flags: bit 0 accepted, bit 1 best so far, bit 2 no uniform drawn) and the proposal that
+// follows it with the normals of the continuation taken
+int sampler_accept_test(int C, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+                        const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
+                        double* d_values, void* stream);
+// the three in one launch (block = chain), for iterations without a covariance refresh between commit and proposal
+int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, const double* d_loglik, const int32_t* d_status,
+                                const double* d_log_u, const double* d_scale_reject, const double* d_scale_accept, double* d_lp,
+                                double* d_best_lp, double* d_scale_sel, uint8_t* d_flags, double* d_values, const double* d_z_uniform,
+                                const double* d_z_plain, int row, void* stream);
+int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,
+                           const uint8_t* d_flags, const double* d_scale, void* stream);
 int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_rows, int n_patch, int P, void* stream);
 int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream);
 int sampler_rank1_catchup(const SamplerState& s, const double* d_gammas, int row0, int n, void* stream);

@@ -67,6 +67,102 @@ __global__ void mh_propose_kernel(const SamplerState s, const DevProblem pb, con
     }
 }
 
+// The accept test of MetropolisHastingsSampler::optimize (:318-331) for every chain, on the device: the evaluation's
+// value goes through safeEvaluate's rule (:65-74; a failed integration, status >= 2, counts as -1e18 like a throwing
+// objective), log_ratio = proposed - current, accepted when log_ratio >= 0 (no uniform drawn) or log(u) < log_ratio.
+// log(u) comes from the host (the chain's mt19937 stream, drawn and logged while the evaluation ran), as do BOTH outcomes
+// of the scale adaptation; the kernel picks.  flags: bit 0 accepted, bit 1 best value of the chain so far, bit 2 the test
+// took no uniform (the next normals are the other continuation's).  values = what the test compared (for the host's
+// bookkeeping, which runs while the NEXT evaluation does).  Comparisons and one subtraction: no rounding to differ in.
+__global__ void mh_accept_kernel(const int C, const double* __restrict__ loglik, const int32_t* __restrict__ status,
+                                 const double* __restrict__ log_u, const double* __restrict__ scale_reject,
+                                 const double* __restrict__ scale_accept, double* lp, double* best_lp, double* scale_sel,
+                                 uint8_t* flags, double* values) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double v = loglik[c];
+    if (status[c] >= 2 || isnan(v) || isinf(v)) v = -1e18;
+    const double log_ratio = v - lp[c];
+    const bool no_uniform = log_ratio >= 0.0;
+    const bool acc = no_uniform || (log_u[c] < log_ratio);
+    uint8_t f = (acc ? 1 : 0) | (no_uniform ? 4 : 0);
+    if (acc) {
+        lp[c] = v;
+        if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
+    }
+    flags[c] = f;
+    scale_sel[c] = acc ? scale_accept[c] : scale_reject[c];
+    values[c] = v;
+}
+
+// proposal with the normals of the continuation the test took (flags bit 2) and the scale it selected
+__global__ void mh_propose_select_kernel(const SamplerState s, const DevProblem pb, const double* z_uniform, const double* z_plain,
+                                         const uint8_t* flags, const double* scale) {
+    const int c = blockIdx.x;
+    const int P = s.P;
+    const double* zc = ((flags[c] & 4) ? z_plain : z_uniform) + (size_t)c * P;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double* Lcol = s.chol + (size_t)c * P * P + i;
+        double sum = 0.0;
+        for (int j = 0; j <= i; ++j) sum += Lcol[(size_t)j * P] * zc[j];
+        const double raw = s.x[(size_t)c * P + i] + scale[c] * sum;
+        s.prop[(size_t)c * P + i] = constrain(raw, pb.lower[i], pb.upper[i], pb.has_bounds[i], pb.constraint_mode);
+    }
+}
+
+// Test, commit and next proposal of one chain in ONE launch (block = chain), for the iterations without a covariance
+// refresh in between (all but one per adaptation period): three dependent small kernels cost the device more in
+// dispatch gaps than in work.  The arithmetic is that of mh_accept_kernel, mh_commit_kernel and
+// mh_propose_select_kernel, in that order.
+__global__ __launch_bounds__(WAVE) void mh_test_commit_propose_kernel(const SamplerState s, const DevProblem pb,
+        const double* __restrict__ loglik, const int32_t* __restrict__ status, const double* __restrict__ log_u,
+        const double* __restrict__ scale_reject, const double* __restrict__ scale_accept, double* lp, double* best_lp, double* scale_sel,
+        uint8_t* flags, double* values, const double* z_uniform, const double* z_plain, const int row) {
+    __shared__ double xs[200];  // P <= 200 (sepaihrd_mh_create)
+    __shared__ double sc_sh;
+    __shared__ int f_sh;
+    const int c = blockIdx.x;
+    const int P = s.P;
+    if (threadIdx.x == 0) {
+        double v = loglik[c];
+        if (status[c] >= 2 || isnan(v) || isinf(v)) v = -1e18;
+        const double log_ratio = v - lp[c];
+        const bool no_uniform = log_ratio >= 0.0;
+        const bool acc = no_uniform || (log_u[c] < log_ratio);
+        int f = (acc ? 1 : 0) | (no_uniform ? 4 : 0);
+        if (acc) {
+            lp[c] = v;
+            if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
+        }
+        const double sc = acc ? scale_accept[c] : scale_reject[c];
+        flags[c] = (uint8_t)f;
+        scale_sel[c] = sc;
+        values[c] = v;
+        f_sh = f;
+        sc_sh = sc;
+    }
+    __syncthreads();
+    const int f = f_sh;
+    const double sc = sc_sh;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const size_t idx = (size_t)c * P + i;
+        double v = s.x[idx];
+        if (f & 1) { v = s.prop[idx]; s.x[idx] = v; }
+        if (f & 2) s.best[idx] = s.prop[idx];
+        s.hist[((size_t)c * s.capacity + row) * P + i] = v;
+        xs[i] = v;
+    }
+    __syncthreads();
+    const double* zc = ((f & 4) ? z_plain : z_uniform) + (size_t)c * P;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const double* Lcol = s.chol + (size_t)c * P * P + i;
+        double sum = 0.0;
+        for (int j = 0; j <= i; ++j) sum += Lcol[(size_t)j * P] * zc[j];
+        const double raw = xs[i] + sc * sum;
+        s.prop[(size_t)c * P + i] = constrain(raw, pb.lower[i], pb.upper[i], pb.has_bounds[i], pb.constraint_mode);
+    }
+}
+
 __global__ void mh_commit_kernel(const SamplerState s, const uint8_t* accept, const int row) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)s.C * s.P) return;
@@ -238,6 +334,30 @@ int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_r
     if (n_patch <= 0) return 0;
     hipLaunchKernelGGL(mh_patch_normals_kernel, dim3(blocks_for((size_t)n_patch * P, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), d_z, d_chain, d_rows, n_patch, P);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_accept_test(int C, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+                        const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
+                        double* d_values, void* stream) {
+    hipLaunchKernelGGL(mh_accept_kernel, dim3(blocks_for((size_t)C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C, d_loglik,
+                       d_status, d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,
+                           const uint8_t* d_flags, const double* d_scale, void* stream) {
+    hipLaunchKernelGGL(mh_propose_select_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, pb, d_z_uniform,
+                       d_z_plain, d_flags, d_scale);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, const double* d_loglik, const int32_t* d_status,
+                                const double* d_log_u, const double* d_scale_reject, const double* d_scale_accept, double* d_lp,
+                                double* d_best_lp, double* d_scale_sel, uint8_t* d_flags, double* d_values, const double* d_z_uniform,
+                                const double* d_z_plain, int row, void* stream) {
+    if (s.P > 200) return -3;
+    hipLaunchKernelGGL(mh_test_commit_propose_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, pb, d_loglik, d_status,
+                       d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values, d_z_uniform, d_z_plain, row);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

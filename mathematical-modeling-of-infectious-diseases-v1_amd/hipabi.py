@@ -60,7 +60,8 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_eval_batch_device", "sepaihrd_eval_batch_begin", "sepaihrd_eval_batch_end", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
     "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
-    "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_stage_normals", "sepaihrd_mh_staging_buffer", "sepaihrd_mh_step", "sepaihrd_mh_read_best", "sepaihrd_mh_busy", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
+    "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_stage_normals", "sepaihrd_mh_staging_buffer", "sepaihrd_mh_step", "sepaihrd_mh_read_best", "sepaihrd_mh_busy", "sepaihrd_mh_set_values", "sepaihrd_mh_test_buffer",
+    "sepaihrd_mh_step_tested", "sepaihrd_mh_fetch_test", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
     "sepaihrd_mh_read_covariance", "sepaihrd_mh_read_proposal", "sepaihrd_mh_history_length",
 )
 

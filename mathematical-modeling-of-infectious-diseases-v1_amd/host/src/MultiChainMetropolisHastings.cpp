@@ -108,9 +108,12 @@ struct CanonicalQueue {
             tail -= head;
             head = 0;
         }
+        // only what is asked for (plus a little): every chain consumes ~80 elements per iteration, and filling the
+        // whole buffer would make ALL chains refill in the same iteration (they start together) -- a 0.5 ms hiccup of
+        // the host every third iteration at 4096 chains, long enough for the device to run dry
         double* const b = buf.data();
-        const size_t cap = buf.size();
-        while (tail < cap) b[tail++] = canonical53(gen);
+        const size_t upto = std::min(buf.size(), n + 16);
+        while (tail < upto) b[tail++] = canonical53(gen);
     }
     double at(size_t i) { ensure(i + 1); return buf[head + i]; }
     void consume(size_t n) { head += n; }
@@ -425,11 +428,11 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         if (rc != SEPAIHRD_OK) throw ModelException("MetropolisHastingsSampler", std::string(what) + ": " + sepaihrd_last_error(ctx));
     };
 
-    // What the host keeps per chain.  The random stream is consumed in the reference's order: the normals
-    // of a proposal, then ONE uniform only if log_ratio < 0 (:327), then the next proposal's normals.
-    // While the device evaluates proposal t the host prepares the draws of proposal t+1 for the likely
-    // outcome of that test (a generator copy takes the uniform first); chains whose test needs no uniform
-    // draw theirs from the untouched stream afterwards.
+    // What the host keeps per chain.  The random stream is consumed in the reference's order: the normals of a
+    // proposal, then ONE uniform only if log_ratio < 0 (:327), then the next proposal's normals.  While the device
+    // evaluates proposal t the host draws BOTH continuations of proposal t + 1 from the chain's queue (with and without
+    // the uniform in front) and hands them to the device, which runs the accept test itself; the host's own state
+    // (stream position, accept window, scale) catches up one evaluation later.
     struct Light {
         CanonicalQueue rng;   // the chain's stream, with look-ahead
         size_t used_likely = 0, used_alt = 0;  // queue elements the two continuations of the pending accept test take
@@ -446,12 +449,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     std::vector<Light> chains(static_cast<size_t>(C));
     const size_t CP = static_cast<size_t>(C) * P;
     std::vector<double> values(static_cast<size_t>(C)), scale(static_cast<size_t>(C));
-    std::vector<double> z_alt(CP);                  // the other branch's normals, drawn for as many chains as the wait allows
-    std::vector<uint8_t> alt_ready(static_cast<size_t>(C));
     double* z_next = sepaihrd_mh_staging_buffer(mh);  // page-locked; re-fetched after every staging (two alternate)
-    std::vector<int32_t> patch_chain(static_cast<size_t>(C));
     std::vector<int32_t> status(static_cast<size_t>(C));
-    std::vector<uint8_t> accept(static_cast<size_t>(C)), needs_patch(static_cast<size_t>(C));
     auto sanitize_all = [&]() {
         for (int c = 0; c < C; ++c)
             values[static_cast<size_t>(c)] = status[static_cast<size_t>(c)] >= 2 ? -1e18 : sanitize(values[static_cast<size_t>(c)]);
@@ -502,8 +501,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     }
 
     const bool profile = std::getenv("SEPAIHRD_MH_PROFILE") != nullptr;
-    double t_launch = 0, t_spec = 0, t_wait = 0, t_acc = 0, t_alt = 0;
-    long alt_drawn = 0, alt_used = 0, alt_missing = 0;
+    double t_launch = 0, t_prepare = 0, t_wait = 0, t_book = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double>(b - a).count();
@@ -514,92 +512,33 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         if (t % adaptation_period_ != 0) return 1;
         return static_cast<size_t>(t) >= static_cast<size_t>(P) + 10 ? 3 : 2;
     };
-    const auto loop_begin = now();
-    if (iterations_ > 1) {  // proposal 1: nothing to commit yet
-        check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
-        z_next = sepaihrd_mh_staging_buffer(mh);
-        check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
-    }
-    for (int t = 1; t < iterations_; ++t) {
-        const auto p1 = now();
-        const bool more = t + 1 < iterations_;
-        // ---- while the device evaluates proposal t: everything of the accept test and of proposal t + 1 that does not
-        //      need the values -- the uniform of the likely branch and its log, the normals that follow it in the
-        //      stream, both outcomes of the scale adaptation with their exp()
+    // The accept test itself runs on the device (sepaihrd_mh_step_tested): the host hands it log(u), both outcomes of
+    // the scale adaptation and the normals of both continuations BEFORE the evaluation is over, so the device goes from
+    // one evaluation to the next without waiting for the host; the host learns the outcome (flags, the values compared)
+    // at the start of the next evaluation and does its bookkeeping for iteration t while evaluation t + 1 runs.
+    check(sepaihrd_mh_set_values(mh, values.data()), "mh_set_values");
+    double* const test = sepaihrd_mh_test_buffer(mh);  // [log_u C][scale if rejected C][scale if accepted C][z_plain C*P]
+    double* const t_log_u = test;
+    double* const t_scale_reject = test + C;
+    double* const t_scale_accept = test + 2 * static_cast<size_t>(C);
+    double* const z_plain = test + 3 * static_cast<size_t>(C);
+    std::vector<uint8_t> flags(static_cast<size_t>(C));
+    // what the host keeps of iteration t once the test's outcome is known (:327-371 and adaptGlobalScale :104-152)
+    auto book = [&](int t, bool drew_next) {
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Light& ch = chains[static_cast<size_t>(c)];
-            // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
-            ch.log_u = std::log(ch.rng.at(0));                                     // :327
-            ch.used_likely = 1 + (more ? draw_normals(ch.rng, 1, &z_next[static_cast<size_t>(c) * P]) : 0);
-            if (adapt_scale_) {
-                bool e;
-                for (int a = 0; a < 2; ++a) {
-                    ch.cand_log_scale[a] = next_log_scale(ch, a == 1, t, &e);
-                    ch.cand_scale[a] = std::exp(ch.cand_log_scale[a]);
-                }
-            }
-        }
-        if (more) {  // lands while the evaluation runs
-            check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
-            z_next = sepaihrd_mh_staging_buffer(mh);
-        }
-        const auto p2a = now();
-        // The device is usually still busy: use the wait to draw the OTHER branch's normals (the stream without the
-        // uniform) chain by chain until the evaluation is done.  A chain that turns out to need them finds them ready
-        // (and its stream advanced exactly as the late draw would have); the others discard them with the stream copy.
-        std::fill(alt_ready.begin(), alt_ready.end(), 0);
-        if (more) {
-            std::atomic<bool> stop{false};
-#pragma omp parallel num_threads(nthreads)
-            {
-#ifdef _OPENMP
-                const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
-#else
-                const int tid = 0, nt = 1;
-#endif
-                // the same blocks of chains as the loops before and after (schedule(static)): a chain's queue stays in
-                // the cache of the core that fills and consumes it
-                const int blk = (C + nt - 1) / nt;
-                const int c_end = std::min(C, (tid + 1) * blk);
-                for (int c = tid * blk; c < c_end; ++c) {
-                    if (tid == 0 && (c % 4) == 0 && !sepaihrd_mh_busy(mh)) stop.store(true, std::memory_order_relaxed);
-                    if (stop.load(std::memory_order_relaxed)) break;
-                    Light& ch = chains[static_cast<size_t>(c)];
-                    ch.used_alt = draw_normals(ch.rng, 0, &z_alt[static_cast<size_t>(c) * P]);
-                    alt_ready[static_cast<size_t>(c)] = 1;
-                }
-            }
-        }
-        const auto p2 = now();
-        check(sepaihrd_mh_fetch(mh, values.data(), status.data()), "mh_fetch");
-        sanitize_all();
-        const auto p3 = now();
-        bool any_best = false;
-#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(|| : any_best)
-        for (int c = 0; c < C; ++c) {
-            Light& ch = chains[static_cast<size_t>(c)];
-            const double prop_lp = values[static_cast<size_t>(c)];
-            const double log_ratio = prop_lp - ch.lp;
-            bool acc = false;
-            needs_patch[static_cast<size_t>(c)] = 0;
-            if (log_ratio >= 0.0) {
-                acc = true;  // no uniform drawn: the next normals come from the untouched stream
-                needs_patch[static_cast<size_t>(c)] = more ? 1 : 0;
-                if (more && !alt_ready[static_cast<size_t>(c)]) ch.used_alt = draw_normals(ch.rng, 0, &z_alt[static_cast<size_t>(c) * P]);
-                ch.rng.consume(more ? ch.used_alt : 0);
-            } else {
-                ch.rng.consume(ch.used_likely);  // the continuation that drew the uniform is the real one; its normals are staged
-                if (ch.log_u < log_ratio) acc = true;
-            }
-            accept[static_cast<size_t>(c)] = acc ? 1 : 0;
+            const uint8_t f = flags[static_cast<size_t>(c)];
+            const bool acc = (f & 1) != 0;
+            // the stream moves by what the continuation taken drew: no uniform (bit 2) -> the plain normals only
+            ch.rng.consume((f & 4) ? (drew_next ? ch.used_alt : 0) : ch.used_likely);
             if (acc) {
-                ch.lp = prop_lp;
+                ch.lp = values[static_cast<size_t>(c)];
                 ch.accepted++;
-                if (ch.lp > ch.best) { ch.best = ch.lp; accept[static_cast<size_t>(c)] |= 2; any_best = true; }  // the device keeps the state
+                if (f & 2) ch.best = ch.lp;  // the device compared against the same best value and keeps the state
             }
             traces_[static_cast<size_t>(c)].push_back(acc ? 1 : 0);
-            if (adapt_scale_) {  // adaptGlobalScale :104-152
+            if (adapt_scale_) {
                 bool emergency_hit;
                 const double ls = next_log_scale(ch, acc, t, &emergency_hit);
                 if (ch.recent_len == 1000) ch.recent_sum -= ch.recent[ch.recent_pos]; else ch.recent_len++;
@@ -610,30 +549,61 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 ch.log_scale = ls;
                 ch.scale = (ls == ch.cand_log_scale[acc ? 1 : 0]) ? ch.cand_scale[acc ? 1 : 0] : std::exp(ls);
             }
-            scale[static_cast<size_t>(c)] = ch.scale;
             if (store_samples_ && (t % thinning_ == 0)) ch.sample_values.push_back(ch.lp);
         }
-        // the rows of the staged normals that belong to the other branch (in z_alt, drawn ahead or just now): their list
-        int n_patch = 0;
-        if (more)
-            for (int c = 0; c < C; ++c)
-                if (needs_patch[static_cast<size_t>(c)]) patch_chain[static_cast<size_t>(n_patch++)] = c;
-        const auto p4 = now();
-        (void)any_best;
-        const auto p5 = now();
-        if (more)  // commit t, adapt, propose t + 1 and launch its evaluation: one call, one upload
-            check(sepaihrd_mh_step(mh, accept.data(), scale.data(), patch_chain.data(), z_alt.data(), n_patch,
-                                   10.0 / ((t + 1) + 100.0), adapt_mode(t + 1)), "mh_step");
-        else
-            check(sepaihrd_mh_commit(mh, accept.data()), "mh_commit");
-        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
-        const auto p6 = now();
-        t_spec += secs(p1, p2a); t_alt += secs(p2a, p2); t_wait += secs(p2, p3); t_acc += secs(p3, p4); t_launch += secs(p5, p6);
-        if (profile)
-            for (int c = 0; c < C; ++c) {
-                alt_drawn += alt_ready[static_cast<size_t>(c)];
-                if (needs_patch[static_cast<size_t>(c)]) { if (alt_ready[static_cast<size_t>(c)]) ++alt_used; else ++alt_missing; }
+    };
+    const auto loop_begin = now();
+    if (iterations_ > 1) {  // proposal 1: nothing to test yet
+        check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
+        z_next = sepaihrd_mh_staging_buffer(mh);
+        check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
+    }
+    for (int t = 1; t < iterations_; ++t) {
+        const auto p0 = now();
+        const bool more = t + 1 < iterations_;
+        if (t > 1) {  // the outcome of test t - 1 (the device ran it when evaluation t - 1 ended)
+            check(sepaihrd_mh_fetch_test(mh, values.data(), flags.data()), "mh_fetch_test");
+            const auto p0b = now();
+            t_wait += secs(p0, p0b);
+            book(t - 1, true);
+            t_book += secs(p0b, now());
+        }
+        const auto p1 = now();
+        // ---- while the device evaluates proposal t: the inputs of test t and both continuations of proposal t + 1
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int c = 0; c < C; ++c) {
+            Light& ch = chains[static_cast<size_t>(c)];
+            // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
+            ch.log_u = std::log(ch.rng.at(0));                                     // :327
+            t_log_u[c] = ch.log_u;
+            ch.used_likely = 1 + (more ? draw_normals(ch.rng, 1, &z_next[static_cast<size_t>(c) * P]) : 0);
+            if (more) ch.used_alt = draw_normals(ch.rng, 0, &z_plain[static_cast<size_t>(c) * P]);
+            if (adapt_scale_) {
+                bool e;
+                for (int a = 0; a < 2; ++a) {
+                    ch.cand_log_scale[a] = next_log_scale(ch, a == 1, t, &e);
+                    ch.cand_scale[a] = std::exp(ch.cand_log_scale[a]);
+                }
+                t_scale_reject[c] = ch.cand_scale[0];
+                t_scale_accept[c] = ch.cand_scale[1];
+            } else {
+                t_scale_reject[c] = t_scale_accept[c] = ch.scale;
             }
+        }
+        if (more) {
+            check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
+            z_next = sepaihrd_mh_staging_buffer(mh);
+        }
+        const auto p2 = now();
+        // test t -> commit -> adapt -> proposal t + 1 -> evaluation t + 1: queued behind evaluation t
+        check(sepaihrd_mh_step_tested(mh, 10.0 / ((t + 1) + 100.0), adapt_mode(t + 1), more ? 0 : 1), "mh_step_tested");
+        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
+        const auto p3 = now();
+        t_prepare += secs(p1, p2); t_launch += secs(p2, p3);
+    }
+    if (iterations_ > 1) {
+        check(sepaihrd_mh_fetch_test(mh, values.data(), flags.data()), "mh_fetch_test");
+        book(iterations_ - 1, false);
     }
     last_loop_seconds_ = secs(loop_begin, now());
     {   // the best states were kept on the device
@@ -643,9 +613,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             chains[static_cast<size_t>(c)].best_x.assign(best_all.begin() + static_cast<size_t>(c) * P, best_all.begin() + static_cast<size_t>(c + 1) * P);
     }
     if (profile)
-        std::fprintf(stderr, "[mh profile] per iteration ms: prepared during the evaluation %.3f  other-branch draws while waiting %.3f  wait for device %.3f  accept + re-draws %.3f  upload + launches %.3f; other-branch rows per iteration: drawn ahead %.0f, used %.0f, drawn late %.0f\n",
-                     1e3 * t_spec / iterations_, 1e3 * t_alt / iterations_, 1e3 * t_wait / iterations_, 1e3 * t_acc / iterations_,
-                     1e3 * t_launch / iterations_, (double)alt_drawn / iterations_, (double)alt_used / iterations_, (double)alt_missing / iterations_);
+        std::fprintf(stderr, "[mh profile] per iteration ms: wait for the previous test %.3f  bookkeeping %.3f  prepare test and both continuations %.3f  upload + launches %.3f\n",
+                     1e3 * t_wait / iterations_, 1e3 * t_book / iterations_, 1e3 * t_prepare / iterations_, 1e3 * t_launch / iterations_);
 
     std::vector<double> rows, covs(static_cast<size_t>(C) * PP);
     const int ns = static_cast<int>(sample_rows.size());
