@@ -648,6 +648,25 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     return results;
 }
 
+// Test hook (tests/test_host_logic.py, no GPU needed): the draws of `rounds` consecutive accept tests of one chain through
+// the look-ahead queue exactly as optimizeChainsOnDevice makes them -- log(u) of the element in front, the P normals of
+// the continuation that takes the uniform (takes_uniform[r] != 0) or of the one that does not, then the stream moves by
+// what that continuation used.  Both continuations are drawn first, as in the loop.
+void canonical_queue_draw_sequence(uint32_t seed, int P, int rounds, const unsigned char* takes_uniform, double* normals,
+                                   double* log_u) {
+    CanonicalQueue q;
+    q.gen.seed(seed);
+    std::vector<double> with_u(static_cast<size_t>(P)), plain(static_cast<size_t>(P));
+    for (int r = 0; r < rounds; ++r) {
+        log_u[r] = std::log(q.at(0));
+        const size_t used_with = 1 + standard_normals_from_queue(q, 1, with_u.data(), P);
+        const size_t used_plain = standard_normals_from_queue(q, 0, plain.data(), P);
+        const bool u = takes_uniform[r] != 0;
+        std::copy((u ? with_u : plain).begin(), (u ? with_u : plain).end(), normals + static_cast<size_t>(r) * P);
+        q.consume(u ? used_with : used_plain);
+    }
+}
+
 std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroupsOnDevice(
     const std::vector<double>& initial, int C, const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives,
     IParameterManager& pm) {

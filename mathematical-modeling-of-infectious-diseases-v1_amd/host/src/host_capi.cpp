@@ -40,7 +40,16 @@ thread_local std::string g_error;
 thread_local double g_last_mh_loop_seconds = 0.0;
 }  // namespace
 
+namespace epidemic {
+void canonical_queue_draw_sequence(uint32_t seed, int P, int rounds, const unsigned char* takes_uniform, double* normals, double* log_u);
+}
+
 extern "C" {
+
+// test hook: see canonical_queue_draw_sequence (MultiChainMetropolisHastings.cpp)
+void host_queue_draw_sequence(uint32_t seed, int P, int rounds, const unsigned char* takes_uniform, double* normals, double* log_u) {
+    epidemic::canonical_queue_draw_sequence(seed, P, rounds, takes_uniform, normals, log_u);
+}
 
 const char* host_last_error(void) { return g_error.c_str(); }
 // iteration loop of this thread's last device-resident sampler run, without set-up and read-back (seconds)

@@ -95,6 +95,49 @@ def test_draw_generator_reproduces_libstdcxx(mm, oracle_py, synth400):
     assert np.array_equal(a, b)
 
 
+def test_sampler_stream_queue_follows_the_generator(mm):
+    """The device-resident sampler reads a chain's mt19937 stream through a look-ahead queue of canonical uniforms that
+    both continuations of an accept test share (host/src/MultiChainMetropolisHastings.cpp: CanonicalQueue).  Driven
+    through its test hook with a random pattern of tests that do / do not take the uniform, it must hand out exactly
+    what libstdc++ would from ONE generator used in the reference's order (MetropolisHastingsSampler.cpp:91-102,327):
+    [the uniform,] then P normals by the polar method with a fresh distribution per proposal."""
+    import ctypes as C
+    import math
+    from mmid_amd import draws, hostabi
+    lib = hostabi.load_library()
+    lib.host_queue_draw_sequence.restype = None
+    lib.host_queue_draw_sequence.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    for seed, P, rounds in ((7, 62, 40), (123456, 5, 120), (3, 1, 60)):
+        takes = (np.random.default_rng(seed).random(rounds) < 0.8).astype(np.uint8)
+        normals = np.empty((rounds, P))
+        log_u = np.empty(rounds)
+        lib.host_queue_draw_sequence(seed, P, rounds, takes.ctypes.data, normals.ctypes.data, log_u.ctypes.data)
+        w = draws.mt19937_words(seed, 4 * rounds * (2 * P + 40))
+        pos = 0
+
+        def canonical():
+            nonlocal pos
+            r = (w[pos] + w[pos + 1] * 4294967296.0) / 18446744073709551616.0
+            pos += 2
+            return math.nextafter(1.0, 0.0) if r >= 1.0 else r
+        for r in range(rounds):
+            keep = pos
+            assert log_u[r] == math.log(canonical())   # the element in front, whether or not the test takes it
+            if not takes[r]:
+                pos = keep
+            ref = np.empty(2 * ((P + 1) // 2))
+            for i in range(0, P, 2):
+                while True:
+                    x = 2.0 * canonical() - 1.0
+                    y = 2.0 * canonical() - 1.0
+                    r2 = x * x + y * y
+                    if not (r2 > 1.0 or r2 == 0.0):
+                        break
+                mult = math.sqrt(-2 * math.log(r2) / r2)
+                ref[i], ref[i + 1] = y * mult, x * mult
+            assert np.array_equal(normals[r], ref[:P]), (seed, r)
+
+
 def test_config_readers_on_synthetic_files(mm, tmp_path):
     cio = mm.config_io
     p = tmp_path / "guess.txt"
