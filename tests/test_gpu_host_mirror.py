@@ -359,3 +359,97 @@ def test_reference_constructor_argument_lists(mm, shipped):
     assert not np.array_equal(got["values"][0, 0], got["values"][0, 1])
     clamped = mm.HostObjective(pb, with_objective=False).apply_constraints(theta[0], 0)[0]
     assert np.array_equal(got["model_back"], clamped)
+
+
+def test_device_accept_test_against_the_host_driven_step(mm, shipped):
+    """sepaihrd_mh_step_tested (accept test, commit and next proposal on the device) against the reference's rule applied
+    on the host to the same values, and against the host-driven entry point fed with that outcome: flags, the values
+    compared, the committed history rows and the next proposals are the same bits.  Covers chains that take no uniform
+    (log_ratio >= 0) and chains whose uniform decides either way."""
+    import ctypes as C
+    from mmid_amd import draws, hipabi
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=mm.CONSTRAINT_REFLECT)
+    Cn, P = 48, pb.n_params
+    lib = hipabi.load_library()
+    vp = C.c_void_p
+    lib.sepaihrd_mh_set_values.argtypes = [vp, vp]
+    lib.sepaihrd_mh_test_buffer.restype = C.POINTER(C.c_double)
+    lib.sepaihrd_mh_test_buffer.argtypes = [vp]
+    lib.sepaihrd_mh_staging_buffer.restype = C.POINTER(C.c_double)
+    lib.sepaihrd_mh_staging_buffer.argtypes = [vp]
+    lib.sepaihrd_mh_stage_normals.argtypes = [vp, vp]
+    lib.sepaihrd_mh_step.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int]
+    lib.sepaihrd_mh_step_tested.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    lib.sepaihrd_mh_fetch_test.argtypes = [vp, vp, vp]
+    rng = np.random.default_rng(11)
+    x0 = draws.jitter_draws(pb, 3, Cn)
+    cov0 = np.diag((0.02 * np.maximum(np.abs(pb.base_theta), 1e-3)) ** 2) + 1e-6 * np.eye(P)
+    z1 = rng.standard_normal((Cn, P))
+    z2u = rng.standard_normal((Cn, P))
+    z2p = rng.standard_normal((Cn, P))
+    scale1 = np.full(Cn, 0.7)
+    scale_rej, scale_acc = np.full(Cn, 0.5), np.full(Cn, 1.25)
+    log_u = np.where(np.arange(Cn) % 3 == 0, -1e300, np.where(np.arange(Cn) % 3 == 1, 0.0, -0.5))
+
+    def sampler():
+        hip = mm.HipObjective(pb)
+        mh = lib.sepaihrd_mh_create(hip.ctx, Cn, 8, x0.ctypes.data, cov0.ctypes.data, 1e-6, 2.38 * 2.38 / P)
+        assert mh
+        lp0, st0 = np.empty(Cn), np.empty(Cn, dtype=np.int32)
+        assert lib.sepaihrd_mh_evaluate_current(mh, lp0.ctypes.data, st0.ctypes.data) == 0
+        lp0 = np.where((st0 >= 2) | ~np.isfinite(lp0), -1e18, lp0)
+        buf = np.ctypeslib.as_array(lib.sepaihrd_mh_staging_buffer(mh), shape=(Cn * P,))
+        buf[:] = z1.ravel()
+        assert lib.sepaihrd_mh_stage_normals(mh, buf.ctypes.data) == 0
+        assert lib.sepaihrd_mh_step(mh, None, scale1.ctypes.data, None, None, 0, 0.1, 0) == 0
+        ll1, st1 = np.empty(Cn), np.empty(Cn, dtype=np.int32)
+        assert lib.sepaihrd_mh_fetch(mh, ll1.ctypes.data, st1.ctypes.data) == 0
+        prop1 = np.empty((Cn, P))
+        assert lib.sepaihrd_mh_read_proposal(mh, prop1.ctypes.data) == 0
+        return hip, mh, lp0, ll1, st1, prop1
+
+    # the reference's rule on the host
+    hipA, mhA, lp0, ll1, st1, prop1 = sampler()
+    v_ref = np.where((st1 >= 2) | ~np.isfinite(ll1), -1e18, ll1)
+    ratio = v_ref - lp0
+    no_u = ratio >= 0.0
+    acc = no_u | (log_u < ratio)
+    assert acc.any() and (~acc).any() and no_u.any() and (~no_u).any()
+    flags_ref = acc.astype(np.uint8) | ((acc & (v_ref > lp0)).astype(np.uint8) << 1) | (no_u.astype(np.uint8) << 2)
+    # A: the device's own test
+    assert lib.sepaihrd_mh_set_values(mhA, lp0.ctypes.data) == 0
+    tb = np.ctypeslib.as_array(lib.sepaihrd_mh_test_buffer(mhA), shape=(3 * Cn + Cn * P,))
+    tb[:Cn], tb[Cn:2 * Cn], tb[2 * Cn:3 * Cn], tb[3 * Cn:] = log_u, scale_rej, scale_acc, z2p.ravel()
+    buf = np.ctypeslib.as_array(lib.sepaihrd_mh_staging_buffer(mhA), shape=(Cn * P,))
+    buf[:] = z2u.ravel()
+    assert lib.sepaihrd_mh_stage_normals(mhA, buf.ctypes.data) == 0
+    assert lib.sepaihrd_mh_step_tested(mhA, 0.1, 0, 0) == 0
+    values, flags = np.empty(Cn), np.empty(Cn, dtype=np.uint8)
+    assert lib.sepaihrd_mh_fetch_test(mhA, values.ctypes.data, flags.ctypes.data) == 0
+    assert np.array_equal(values, v_ref) and np.array_equal(flags, flags_ref)
+    propA = np.empty((Cn, P))
+    assert lib.sepaihrd_mh_read_proposal(mhA, propA.ctypes.data) == 0
+    rows = np.array([0, 1], dtype=np.int32)
+    histA = np.empty((Cn, 2, P))
+    assert lib.sepaihrd_mh_read_history(mhA, rows.ctypes.data, 2, histA.ctypes.data) == 0
+    assert np.array_equal(histA[:, 1], np.where(acc[:, None], prop1, x0))
+    # B: the host-driven step with that outcome
+    hipB, mhB, lp0b, ll1b, st1b, prop1b = sampler()
+    assert np.array_equal(ll1b, ll1) and np.array_equal(prop1b, prop1)
+    buf = np.ctypeslib.as_array(lib.sepaihrd_mh_staging_buffer(mhB), shape=(Cn * P,))
+    buf[:] = z2u.ravel()
+    assert lib.sepaihrd_mh_stage_normals(mhB, buf.ctypes.data) == 0
+    scale2 = np.where(acc, scale_acc, scale_rej)
+    patch = np.nonzero(no_u)[0].astype(np.int32)
+    accept_b = (flags_ref & 3).astype(np.uint8)
+    assert lib.sepaihrd_mh_step(mhB, accept_b.ctypes.data, scale2.ctypes.data, patch.ctypes.data, z2p.ctypes.data, len(patch), 0.1, 0) == 0
+    ll2 = np.empty(Cn)
+    assert lib.sepaihrd_mh_fetch(mhB, ll2.ctypes.data, None) == 0
+    propB = np.empty((Cn, P))
+    assert lib.sepaihrd_mh_read_proposal(mhB, propB.ctypes.data) == 0
+    assert np.array_equal(propA, propB)
+    ll2a = np.empty(Cn)
+    assert lib.sepaihrd_mh_fetch(mhA, ll2a.ctypes.data, None) == 0
+    assert np.array_equal(ll2a, ll2)
+    lib.sepaihrd_mh_destroy(mhA)
+    lib.sepaihrd_mh_destroy(mhB)
