@@ -165,7 +165,7 @@ struct SamplerState {
     double* x;      // [C][P] current state
     double* prop;   // [C][P] last proposal (after applyConstraints)
     double* cov;    // [C][P][P] proposal covariance, row-major
-    double* chol;   // [C][P][P] its lower Cholesky factor, column-major: L(i, j) at [j][i] (coalesced in the proposal)
+    double* chol;   // [C] x (P P allocated) its lower Cholesky factor, the lower triangle column by column: L(i, j), i >= j, at j P - j (j - 1) / 2 + (i - j)
     double* mean;   // [C][P] running mean
     double* hist;   // [C][capacity][P] every state of every chain
     double* best;   // [C][P] the best state so far (updated by commit where bit 1 of the chain's accept byte is set)
