@@ -282,6 +282,20 @@ def test_device_resident_sampler_state_matches_host_loop(mm, oracle_py, shipped)
     assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"])
 
 
+@pytest.mark.parametrize("iters", [1, 2, 3, 5])
+def test_device_resident_sampler_short_runs(mm, shipped, iters):
+    """The ends of the device-resident loop (first proposal without a test, last test without a proposal, the
+    bookkeeping that trails by one evaluation): runs of 1, 2, 3 and 5 iterations equal the host loop."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 5, 4)
+    kw = dict(seed=29, iterations=iters, burn_in=0, adaptation_period=2, thinning=1)
+    host = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values"):
+        assert np.array_equal(dev[k], host[k]), k
+
+
 def test_chain_groups_on_separate_streams_give_the_single_group_result(mm, oracle_py, shipped):
     """optimizeChainGroupsOnDevice: 7 chains in 3 ragged groups (one context, stream and host thread each)
     == one group; chain c draws from mt19937(seed + c) whatever the grouping."""
