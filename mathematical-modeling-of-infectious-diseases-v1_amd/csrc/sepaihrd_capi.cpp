@@ -64,6 +64,10 @@ struct sepaihrd_ctx {
     hipEvent_t busy_event = nullptr;
     hipStream_t busy_stream = nullptr;
     bool busy_valid = false;
+    // set while a sampler object drives this context from its own stream (one sampler per context, header): the
+    // evaluation launches of its iteration loop then carry no fence event -- every marker between two kernels of a stream
+    // is dispatch latency, and the sampler's period is one evaluation plus exactly those gaps
+    bool fence_elided = false;
     // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
     bool timing = false;
     int timing_period = 1;     // events around every timing_period-th launch sequence only
@@ -162,6 +166,8 @@ bool stream_is_capturing(hipStream_t st) {
 // Inside a stream capture nothing is recorded or waited for (the captured graph owns its ordering).
 int fence_before(sepaihrd_ctx* c, hipStream_t st) {
     if (!c->busy_valid || c->busy_stream == st || stream_is_capturing(st)) return SEPAIHRD_OK;
+    // records were elided on the busy stream (a sampler's loop): mark its end now, lazily, for this other stream
+    if (c->fence_elided) (void)hipEventRecord(c->busy_event, c->busy_stream);
     if (hipStreamWaitEvent(st, c->busy_event, 0) != hipSuccess) {
         c->last_error = "hipStreamWaitEvent on the context's previous evaluation failed";
         return SEPAIHRD_E_HIP;
@@ -169,6 +175,7 @@ int fence_before(sepaihrd_ctx* c, hipStream_t st) {
     return SEPAIHRD_OK;
 }
 void fence_after(sepaihrd_ctx* c, hipStream_t st) {
+    if (c->fence_elided && c->busy_valid && c->busy_stream == st) return;  // the previous record already names this stream
     if (stream_is_capturing(st)) return;
     if (!c->busy_event && hipEventCreateWithFlags(&c->busy_event, hipEventDisableTiming) != hipSuccess) {
         c->busy_event = nullptr;
@@ -899,6 +906,7 @@ struct sepaihrd_mh {
     void* d_test_out = nullptr;
     void* h_test_out = nullptr;
     hipEvent_t ev_test_up = nullptr, ev_tested = nullptr, ev_fetched = nullptr, ev_proposed = nullptr;
+    hipEvent_t ev_last_proposed = nullptr;  // whichever of the two marks the end of the last proposal
     bool values_set = false, test_pending = false, proposed_once = false;
     uint8_t* d_pack = nullptr;
     size_t pack_bytes = 0, off_scale = 0, off_chain = 0, off_rows = 0;
@@ -1075,12 +1083,14 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         return nullptr;
     }
     mh->rows = 1;
+    ctx->fence_elided = true;
     return mh;
 }
 
 void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (!mh) return;
     (void)hipSetDevice(mh->ctx->device);
+    mh->ctx->fence_elided = false;
     if (mh->copy_stream) { (void)hipStreamSynchronize(mh->copy_stream); (void)hipStreamDestroy(mh->copy_stream); }
     if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
@@ -1211,7 +1221,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     const size_t CP = (size_t)C * P;
     // the test's inputs travel on the copy stream while the evaluation still runs; they may not overwrite what the
     // previous proposal is reading
-    if (mh->proposed_once) HIP_TRY(hipStreamWaitEvent(cs, mh->ev_proposed, 0), ctx, return SEPAIHRD_E_HIP);
+    if (mh->proposed_once) HIP_TRY(hipStreamWaitEvent(cs, mh->ev_last_proposed, 0), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpyAsync(mh->d_test, mh->h_test, (3 * (size_t)C + (last ? 0 : CP)) * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
             return SEPAIHRD_E_HIP);
     HIP_TRY(hipEventRecord(mh->ev_test_up, cs), ctx, return SEPAIHRD_E_HIP);
@@ -1220,15 +1230,15 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     uint8_t* const d_flags = reinterpret_cast<uint8_t*>(d_values + C);
     if (!last && adapt <= 1) {
         // no covariance refresh between commit and proposal: test, commit and proposal in one launch
-        HIP_TRY(hipStreamWaitEvent(st, mh->ev_staged, 0), ctx, return SEPAIHRD_E_HIP);  // the staged normals have landed
+        // (the staged normals landed before the test's inputs: same copy stream, staged first -- ev_test_up covers them)
         if (sampler_test_commit_propose(mh->st, ctx->dp, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C,
                                         mh->d_lp, mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, mh->d_z_stage,
                                         mh->d_test + 3 * (size_t)C, mh->rows, st) != 0) {
             ctx->last_error = "mh_step_tested: launch failed";
             return SEPAIHRD_E_HIP;
         }
-        HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipEventRecord(mh->ev_proposed, st), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);  // one marker: tested AND proposed
+        mh->ev_last_proposed = mh->ev_tested;
         HIP_TRY(hipStreamWaitEvent(cs, mh->ev_tested, 0), ctx, return SEPAIHRD_E_HIP);
         HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
                 return SEPAIHRD_E_HIP);
@@ -1261,6 +1271,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     rc = sampler_propose_select(mh->st, ctx->dp, mh->d_z_stage, mh->d_test + 3 * (size_t)C, d_flags, mh->d_scale_sel, st);
     if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipEventRecord(mh->ev_proposed, st), ctx, return SEPAIHRD_E_HIP);
+    mh->ev_last_proposed = mh->ev_proposed;
     mh->proposed_once = true;
     std::swap(mh->d_z, mh->d_z_stage);
     mh->staged = false;
