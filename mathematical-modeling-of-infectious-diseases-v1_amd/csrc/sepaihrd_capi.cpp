@@ -64,10 +64,10 @@ struct sepaihrd_ctx {
     hipEvent_t busy_event = nullptr;
     hipStream_t busy_stream = nullptr;
     bool busy_valid = false;
-    // set while a sampler object drives this context from its own stream (one sampler per context, header): the
-    // evaluation launches of its iteration loop then carry no fence event -- every marker between two kernels of a stream
-    // is dispatch latency, and the sampler's period is one evaluation plus exactly those gaps
-    bool fence_elided = false;
+    // a stream the LIBRARY owns (a sampler's) on which launches after the first record nothing: every marker between two
+    // kernels of a stream is dispatch latency (3-5 us each in the sampler loop).  The event is re-recorded lazily when
+    // another stream asks (fence_before); only for an owned stream, whose handle is known to be alive
+    hipStream_t lazy_stream = nullptr;
     // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
     bool timing = false;
     int timing_period = 1;     // events around every timing_period-th launch sequence only
@@ -166,8 +166,9 @@ bool stream_is_capturing(hipStream_t st) {
 // Inside a stream capture nothing is recorded or waited for (the captured graph owns its ordering).
 int fence_before(sepaihrd_ctx* c, hipStream_t st) {
     if (!c->busy_valid || c->busy_stream == st || stream_is_capturing(st)) return SEPAIHRD_OK;
-    // records were elided on the busy stream (a sampler's loop): mark its end now, lazily, for this other stream
-    if (c->fence_elided) (void)hipEventRecord(c->busy_event, c->busy_stream);
+    // launches after the first on a sampler's stream recorded nothing: mark the end of what is queued there now, for
+    // this other stream to wait on
+    if (c->lazy_stream != nullptr && c->busy_stream == c->lazy_stream) (void)hipEventRecord(c->busy_event, c->busy_stream);
     if (hipStreamWaitEvent(st, c->busy_event, 0) != hipSuccess) {
         c->last_error = "hipStreamWaitEvent on the context's previous evaluation failed";
         return SEPAIHRD_E_HIP;
@@ -175,7 +176,7 @@ int fence_before(sepaihrd_ctx* c, hipStream_t st) {
     return SEPAIHRD_OK;
 }
 void fence_after(sepaihrd_ctx* c, hipStream_t st) {
-    if (c->fence_elided && c->busy_valid && c->busy_stream == st) return;  // the previous record already names this stream
+    if (c->busy_valid && c->busy_stream == st && st == c->lazy_stream) return;  // recorded lazily (fence_before)
     if (stream_is_capturing(st)) return;
     if (!c->busy_event && hipEventCreateWithFlags(&c->busy_event, hipEventDisableTiming) != hipSuccess) {
         c->busy_event = nullptr;
@@ -1083,16 +1084,21 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         return nullptr;
     }
     mh->rows = 1;
-    ctx->fence_elided = true;
+    ctx->lazy_stream = mh->stream;
     return mh;
 }
 
 void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (!mh) return;
     (void)hipSetDevice(mh->ctx->device);
-    mh->ctx->fence_elided = false;
     if (mh->copy_stream) { (void)hipStreamSynchronize(mh->copy_stream); (void)hipStreamDestroy(mh->copy_stream); }
-    if (mh->stream) { (void)hipStreamSynchronize(mh->stream); (void)hipStreamDestroy(mh->stream); }
+    if (mh->stream) {
+        (void)hipStreamSynchronize(mh->stream);
+        sepaihrd_ctx* ctx = mh->ctx;
+        if (ctx->lazy_stream == mh->stream) ctx->lazy_stream = nullptr;
+        if (ctx->busy_stream == mh->stream) { ctx->busy_valid = false; ctx->busy_stream = nullptr; }  // all of it is done
+        (void)hipStreamDestroy(mh->stream);
+    }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
     for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed}) if (e) (void)hipEventDestroy(e);
     if (mh->h_pack) (void)hipHostFree(mh->h_pack);
