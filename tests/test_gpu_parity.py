@@ -538,3 +538,84 @@ def test_fp32_arm_limits_are_errors_not_fallbacks(mm, shipped):
     hip.set_initial_state_mode(0)
     ref = mm.HipObjective(shipped).eval_batch(np.asarray(shipped.base_theta)[None, :])
     assert np.array_equal(hip.eval_batch(np.asarray(shipped.base_theta)[None, :])["loglik"], ref["loglik"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The cases of the reference's own test file for this path (tests/model/SEPAIHRDObjectivefunctionTest.cpp), on the
+# reference's fixture (n = 4, kappa schedule, multiplier branch, 30 daily points), each against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _poisson_obs(oracle_py, pb, seed):
+    """Observations the way the reference's fixture makes them (:217-242): Poisson draws around the base trajectory."""
+    base = oracle_py.Oracle(pb).eval_batch(pb.base_theta[None, :], want_traj=True)["traj"][0]
+    n = len(pb.N)
+    rs = np.random.RandomState(seed)
+    inc = lambda c: np.maximum(np.diff(base[:, c * n:(c + 1) * n], axis=0, prepend=base[:1, c * n:(c + 1) * n]), 0.0)
+    return (rs.poisson(inc(9)).astype(float), rs.poisson(inc(10)).astype(float), rs.poisson(inc(8)).astype(float))
+
+
+def test_reference_suite_zero_data_and_repeatability(mm, oracle_py, ref_fixture):
+    """ZeroDataTest (:384): all observations 0 -> a finite value, the oracle's; ParallelConsistencyTest (:492): five
+    evaluations of one vector give one value; SensitivityTest (:368): another beta gives another value."""
+    pb = ref_fixture.with_(arith=mm.ARITH_STRICT)
+    zero = pb.with_(obs_H=np.zeros_like(pb.obs_H), obs_ICU=np.zeros_like(pb.obs_ICU), obs_D=np.zeros_like(pb.obs_D))
+    got = mm.HipObjective(zero).eval_batch(zero.base_theta[None, :])
+    ref = oracle_py.Oracle(zero).eval_batch(zero.base_theta[None, :])
+    assert got["status"][0] == 0 and np.isfinite(got["loglik"][0]) and got["loglik"][0] < 0
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+    hip = mm.HipObjective(pb)
+    five = [hip.calculate(pb.base_theta) for _ in range(5)]
+    assert len(set(five)) == 1
+    th = pb.base_theta.copy()
+    th[pb.param_names.index("beta")] *= 1.1
+    assert hip.calculate(th) != five[0]
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 40.0])
+def test_reference_suite_extreme_beta(mm, oracle_py, ref_fixture, scale):
+    """ExtremeParameterTest (:510): a transmission rate far below / far above the fitted one still gives the oracle's
+    value (or both sides' failure sentinel)."""
+    pb = ref_fixture.with_(arith=mm.ARITH_STRICT, bounds={})
+    th = pb.base_theta.copy()
+    th[pb.param_names.index("beta")] *= scale
+    got = mm.HipObjective(pb).eval_batch(th[None, :])
+    ref = oracle_py.Oracle(pb).eval_batch(th[None, :])
+    assert np.array_equal(got["status"], ref["status"])
+    if ref["status"][0] == 0:
+        np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+        assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    else:
+        assert got["loglik"][0] == mm.LOWEST
+
+
+@pytest.mark.parametrize("step,days", [(0.1, 30.0), (1.0, 365.0)])
+def test_reference_suite_dense_and_long_grids(mm, oracle_py, ref_fixture, step, days):
+    """DenseTimeGridTest (:414, 0.1-day outputs) and LongSimulationTest (:566, a 365-day grid): more outputs than RK steps
+    in the first, the whole kappa schedule in the second; values and step counts are the oracle's."""
+    times = np.round(np.arange(0.0, days + 0.5 * step, step), 10)
+    T = len(times)
+    n = len(ref_fixture.N)
+    pb = ref_fixture.with_(arith=mm.ARITH_STRICT, times=times, obs_H=np.zeros((T, n)), obs_ICU=np.zeros((T, n)), obs_D=np.zeros((T, n)))
+    oH, oI, oD = _poisson_obs(oracle_py, pb, 42)
+    pb = pb.with_(obs_H=oH, obs_ICU=oI, obs_D=oD)
+    rs = np.random.RandomState(5)
+    theta = pb.base_theta[None, :] * (1 + 0.05 * rs.standard_normal((6, pb.n_params)))
+    got = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
+    ref = oracle_py.Oracle(pb).eval_batch(theta, want_traj=True)
+    assert np.all(got["status"] == 0) and np.array_equal(got["status"], ref["status"])
+    assert np.array_equal(got["n_accept"], ref["n_accept"]) and np.array_equal(got["n_reject"], ref["n_reject"])
+    np.testing.assert_allclose(got["loglik"], ref["loglik"], rtol=1e-10)
+    assert rel_state_err(got["traj"], ref["traj"], pb).max() < 1e-9
+
+
+def test_reference_suite_streams_enter_separately(mm, oracle_py, ref_fixture):
+    """IndividualLikelihoodComponentsTest / the per-stream tests (:528, :604): changing one stream's observations moves
+    exactly that stream's part of the log-likelihood."""
+    pb = ref_fixture.with_(arith=mm.ARITH_STRICT)
+    base = mm.HipObjective(pb).eval_batch(pb.base_theta[None, :])["ll_parts"][0]
+    for k, name in enumerate(("obs_H", "obs_ICU", "obs_D")):
+        other = pb.with_(**{name: getattr(pb, name) + 1.0})
+        parts = mm.HipObjective(other).eval_batch(other.base_theta[None, :])["ll_parts"][0]
+        ref = oracle_py.Oracle(other).eval_batch(other.base_theta[None, :])["ll_parts"][0]
+        np.testing.assert_allclose(parts, ref, rtol=1e-10)
+        for j in range(3):
+            assert (parts[j] != base[j]) == (j == k)
