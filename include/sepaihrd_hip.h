@@ -53,7 +53,11 @@
 extern "C" {
 #endif
 
-#define SEPAIHRD_ABI_VERSION 1
+/* 2: sepaihrd_problem.reserved0 became `precision`; per-chain status SEPAIHRD_STATUS_PIPELINE; the accept byte of
+ *    sepaihrd_mh_commit / _step is a bit field; sepaihrd_mh_create takes a struct sepaihrd_mh_config: ring of newest states,
+ *    thinned samples and running co-moments instead of the whole chain history; sepaihrd_mh_read_samples /
+ *    _sample_count / _summary_records / _read_moments added. */
+#define SEPAIHRD_ABI_VERSION 2
 #define SEPAIHRD_NUM_COMPARTMENTS 11 /* S,E,P,A,I,H,ICU,R,D,CumH,CumICU (ModelConstants.hpp:18) */
 #define SEPAIHRD_MAX_AGE_CLASSES 64  /* one lane per (chain, age class); 64/n chains per wavefront */
 #define SEPAIHRD_MAX_SCHEDULE 32     /* max beta / kappa periods */
@@ -92,6 +96,9 @@ extern "C" {
 #define SEPAIHRD_STATUS_STEP_FAILURE 2 /* odeint step_adjustment_error (500 rejections): the reference
                                           lets SimulationException propagate out of calculate() */
 #define SEPAIHRD_STATUS_STEP_BUDGET 3  /* build-side guard: max_attempts exhausted */
+#define SEPAIHRD_STATUS_PIPELINE 4     /* build-side guard: the hand-off between the integrating wave and the wave that
+                                          evaluates its Poisson terms (batches of <= 4096 chains) timed out; no value was
+                                          produced.  Like 2 and 3 the C++ adapter raises SimulationException for it */
 
 /* theta -> model field map (what the reference resolves from parameter NAMES on every call) */
 enum sepaihrd_field {
@@ -270,30 +277,62 @@ int sepaihrd_ensemble_quantiles(sepaihrd_ctx *ctx, const double *theta, int S, c
  * MetropolisHastingsSampler (src/sir_age_structured/optimizers/MetropolisHastingsSampler.cpp:201-412)
  * keeps per chain: current state, proposal covariance and its Cholesky factor, running mean and the
  * whole chain history, from which the covariance is recomputed every adaptation period (:168-199,
- * O(t P^2)).  For C lock-step chains that state (C t P doubles of history) and that work live next to the
- * likelihood kernel.  The caller keeps what must stay serial per chain: the std::mt19937 stream (its
- * draw order depends on the accept test), the accept decision and the scalar scale adaptation.
- * Every sum runs in the reference's order without contraction: a host loop doing the same arithmetic
- * gets the same bits.
+ * O(t P^2) per refresh, t P doubles of history).  For C lock-step chains that state and that work live next to the
+ * likelihood kernel -- but not the whole history: at the reference's own settings (100 000 iterations,
+ * adaptation_period 100, data/configuration/mcmc_settings.txt) the walk over the history, not the likelihood,
+ * would set the pace, and 4096 x 100 000 x 62 doubles are 203 GB.  The history is read in three places only
+ * (its newest state :157, all of it :168-199, every thinning-th state :357-360), so the sampler keeps
+ *   - a ring of the newest `adaptation_window` states (queued updates read it),
+ *   - running sums of ALL states: their plain sum, added in the order of the reference's mean loop (:171-174: the
+ *     refreshed running mean is the reference's bit for bit), and Welford's centred second moment
+ *       n-th state x, d = x - mean:   m2_ij += ((n-1)/n) (d_i d_j),   mean_i += d_i (1/n)
+ *     from which a refresh is cov = scaling m2 / (len - 1) + eps I in O(P^2) whatever len is (the reference forms the
+ *     same matrix as centered^T centered through Eigen's GEMM, whose summation order nothing in its tree pins),
+ *   - the thinned samples.
+ * SEPAIHRD_MH_COV_TWO_PASS keeps every state in the ring and refreshes with the reference's two literal passes, for
+ * comparison (the two covariances agree to ~1e-13 relative; the oracle restates both).
+ * The caller keeps what must stay serial per chain: the std::mt19937 stream (its draw order depends on the accept
+ * test) and the scalar scale adaptation.  Every sum runs in a fixed order without contraction: a host loop doing
+ * the same arithmetic gets the same bits.
  *
  *   create    x0 [C][P] host; cov0 [P][P] row-major host = the initial covariance of EVERY chain,
  *             regularisation already added (:219-237); its Cholesky factor is taken on the device,
- *             0.1 I when it is not positive definite (:240-246); history row 0 = x0, mean = x0.
- *             capacity = history rows per chain (the number of iterations incl. iteration 0).
+ *             0.1 I when it is not positive definite (:240-246); state 0 = x0, mean = x0.
  *   evaluate_current  log-likelihood of the current states (:257)
  *   propose   prop = applyConstraints(x + scale_c L_c z_c) for every chain, evaluated: z [C][P], scale [C],
  *             loglik [C], status [C] (nullable) host (:91-102,309-312).  loglik == NULL only launches: the
  *             caller overlaps its own work with the evaluation and collects the values with fetch
- *   commit    accept [C] (0/1) host: x <- prop where set, the state is appended to the history (:332-371)
- *   adapt     rank-one update with gamma from the newest history row (:154-166); if refresh != 0 the
- *             adaptation-period step (:283-301): full two-pass recompute when recompute_full != 0
- *             (caller checks history >= P + 10), then the Cholesky factor of cov + eps I, kept on success
- *   read_history / read_covariance   rows of the history [C][n_rows][P], covariances [C][P][P]
+ *   commit    accept [C] host (bit 0 = accepted, bit 1 = best state of the chain so far): x <- prop where bit 0 is
+ *             set, the state joins the ring and, every thinning-th one, the samples (:332-371)
+ *   adapt     rank-one update (:154-166) with gamma, reading the NEWEST state (the last one committed); updates are
+ *             queued with the state they read and applied in order when the covariance is next looked at, so any
+ *             pattern of commit / adapt calls gives what immediate updates would.  refresh != 0: the
+ *             adaptation-period step (:283-301): full recompute when recompute_full != 0 (caller checks
+ *             history >= P + 10), then the Cholesky factor of cov + eps I, kept on success
+ *   read_history   states still among the newest `window`, [C][n_rows][P];  read_samples  the thinned samples
+ *             first .. first + count - 1, [C][count][P];  read_covariance  [C][P][P];  read_moments  Welford mean [C][P]
+ *             and centred second moment [C][P][P] (entries j <= i) of all states so far
+ *   summary_records   SURVEY 8(e)'s per-chain record [P means | P variances | best value | accepted proposals] over the
+ *             samples first_sample .. (ResultAggregator.cpp:35-172 works on such per-chain / per-batch summaries):
+ *             out [C][2 P + 2] host and / or d_out, the same on the device (for a collective); needs the accept test
+ *             on the device (step_tested), which tracks best value and accept count
  * P <= 200 (the factorisation keeps a packed lower triangle in LDS).  A sampler object borrows its context: destroy it before the context, and use one sampler per
  * context at a time (it evaluates through the context's workspace on its own stream). */
+#define SEPAIHRD_MH_COV_RUNNING 0   /* covariance refresh from running co-moments: O(P^2), no history */
+#define SEPAIHRD_MH_COV_TWO_PASS 1  /* recomputeFullCovariance as written: two passes over every state of the chain */
+typedef struct sepaihrd_mh_config {
+    int32_t chains;            /* C */
+    int32_t iterations;        /* states a chain will commit, state 0 included (mcmc_iterations) */
+    int32_t thinning;          /* states t with t % thinning == 0 are kept as samples (:357); <= 0: no samples kept */
+    int32_t adaptation_window; /* ring of newest states per chain; >= the adaptation period keeps every catch-up on the
+                                  refresh itself (smaller only costs extra launches); <= 0: 128 */
+    int32_t covariance_mode;   /* SEPAIHRD_MH_COV_* */
+    int32_t reserved;          /* 0 */
+    double reg_eps;            /* regularization_epsilon */
+    double scaling_factor;     /* 2.38^2 / P */
+} sepaihrd_mh_config;
 typedef struct sepaihrd_mh sepaihrd_mh;
-sepaihrd_mh *sepaihrd_mh_create(sepaihrd_ctx *ctx, int C, int capacity, const double *x0, const double *cov0,
-                                double reg_eps, double scaling_factor);
+sepaihrd_mh *sepaihrd_mh_create(sepaihrd_ctx *ctx, const sepaihrd_mh_config *config, const double *x0, const double *cov0);
 void sepaihrd_mh_destroy(sepaihrd_mh *mh);
 int sepaihrd_mh_evaluate_current(sepaihrd_mh *mh, double *loglik, int32_t *status);
 int sepaihrd_mh_propose(sepaihrd_mh *mh, const double *z, const double *scale, double *loglik, int32_t *status);
@@ -336,7 +375,11 @@ int sepaihrd_mh_fetch_test(sepaihrd_mh *mh, double *values, uint8_t *flags);
 int sepaihrd_mh_commit(sepaihrd_mh *mh, const uint8_t *accept);
 int sepaihrd_mh_adapt(sepaihrd_mh *mh, double gamma, int refresh, int recompute_full);
 int sepaihrd_mh_read_history(sepaihrd_mh *mh, const int32_t *rows, int n_rows, double *out);
+int sepaihrd_mh_sample_count(const sepaihrd_mh *mh);
+int sepaihrd_mh_read_samples(sepaihrd_mh *mh, int first, int count, double *out);
 int sepaihrd_mh_read_covariance(sepaihrd_mh *mh, double *cov);
+int sepaihrd_mh_read_moments(sepaihrd_mh *mh, double *mean, double *m2);
+int sepaihrd_mh_summary_records(sepaihrd_mh *mh, int first_sample, double *out, double *d_out);
 /* commit / step read the accept byte as bit 0 = accepted, bit 1 = "this proposal is the chain's best state so far"
  * (the caller's bookkeeping): the best states are kept on the device, [C][P], initially x0 */
 int sepaihrd_mh_read_best(sepaihrd_mh *mh, double *best);

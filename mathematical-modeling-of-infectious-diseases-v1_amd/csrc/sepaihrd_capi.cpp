@@ -911,43 +911,82 @@ struct sepaihrd_mh {
     bool values_set = false, test_pending = false, proposed_once = false;
     uint8_t* d_pack = nullptr;
     size_t pack_bytes = 0, off_scale = 0, off_chain = 0, off_rows = 0;
-    // rank-one covariance updates not yet applied (see mh_rank1_catchup_cov_kernel): consecutive history rows from
-    // pending_row0, one gamma each
+    // rank-one covariance updates not yet applied (see mh_rank1_catchup_cov_kernel): the state each one reads and its
+    // gamma, in the order they were asked for.  Uploaded as [rows n int32 | gammas n doubles] from a page-locked buffer.
+    std::vector<int32_t> pending_row;
     std::vector<double> pending_gamma;
-    int pending_row0 = 0;
-    double* d_gammas = nullptr;
-    size_t gammas_cap = 0;
+    void* d_r1 = nullptr;
+    void* h_r1 = nullptr;
+    size_t r1_cap = 0;
+    hipEvent_t ev_r1 = nullptr;  // the last upload out of h_r1 has been copied
+    bool r1_in_flight = false;
+    // states [mom_rows, rows) have not entered the running sums yet (see mh_moments_catchup_kernel)
+    int mom_rows = 0;
+    int covariance_mode = SEPAIHRD_MH_COV_RUNNING;
+    int iterations = 0;
+    double* d_summary = nullptr;
     std::vector<void*> allocs;
 };
 
 namespace {
-// queue the rank-one update that precedes the next proposal (history row rows - 1 with this gamma)
+// queue the rank-one update that precedes the next proposal: it reads the newest state (row rows - 1) with this gamma
 void mh_queue_rank1(sepaihrd_mh* mh, double gamma) {
-    if (mh->pending_gamma.empty()) mh->pending_row0 = mh->rows - 1;
+    mh->pending_row.push_back(mh->rows - 1);
     mh->pending_gamma.push_back(gamma);
 }
-// apply the queued updates in order (someone is about to read the covariance)
+// apply the queued updates in order (someone is about to read the covariance, or the ring is about to overwrite a
+// state they read)
 int mh_flush_rank1(sepaihrd_mh* mh) {
     const size_t n = mh->pending_gamma.size();
     if (n == 0) return 0;
-    sepaihrd_ctx* ctx = mh->ctx;
-    if (n > mh->gammas_cap) {
-        if (mh->d_gammas) (void)hipFree(mh->d_gammas);
-        mh->d_gammas = nullptr;
-        mh->gammas_cap = 0;
-        if (hipMalloc((void**)&mh->d_gammas, std::max<size_t>(n, 256) * sizeof(double)) != hipSuccess) return -3;
-        mh->gammas_cap = std::max<size_t>(n, 256);
+    for (size_t k = 0; k < n; ++k)  // every state still in the ring (mh_before_commit keeps it so)
+        if (mh->pending_row[k] < 0 || mh->pending_row[k] >= mh->rows || mh->pending_row[k] < mh->rows - mh->st.window) return -1;
+    if (mh->r1_in_flight) {  // the page-locked buffer is still the source of the previous upload
+        if (hipEventSynchronize(mh->ev_r1) != hipSuccess) return -3;
+        mh->r1_in_flight = false;
     }
-    // pageable source: the copy is complete for the host when the call returns, the vector can be cleared
-    if (hipMemcpyAsync(mh->d_gammas, mh->pending_gamma.data(), n * sizeof(double), hipMemcpyHostToDevice, mh->stream) != hipSuccess) return -3;
-    if (hipStreamSynchronize(mh->stream) != hipSuccess) return -3;
-    const int rc = sampler_rank1_catchup(mh->st, mh->d_gammas, mh->pending_row0, (int)n, mh->stream);
+    if (n > mh->r1_cap) {
+        const size_t cap = std::max<size_t>(2 * n, 256);
+        if (mh->d_r1) (void)hipFree(mh->d_r1);
+        if (mh->h_r1) (void)hipHostFree(mh->h_r1);
+        mh->d_r1 = mh->h_r1 = nullptr;
+        mh->r1_cap = 0;
+        if (hipMalloc(&mh->d_r1, cap * (sizeof(double) + sizeof(int32_t))) != hipSuccess) return -3;
+        if (hipHostMalloc(&mh->h_r1, cap * (sizeof(double) + sizeof(int32_t)), hipHostMallocDefault) != hipSuccess) return -3;
+        mh->r1_cap = cap;
+    }
+    // [gammas cap doubles | rows cap int32]: both aligned whatever n
+    std::memcpy(mh->h_r1, mh->pending_gamma.data(), n * sizeof(double));
+    std::memcpy(static_cast<char*>(mh->h_r1) + mh->r1_cap * sizeof(double), mh->pending_row.data(), n * sizeof(int32_t));
+    if (hipMemcpyAsync(mh->d_r1, mh->h_r1, mh->r1_cap * sizeof(double) + n * sizeof(int32_t), hipMemcpyHostToDevice, mh->stream) != hipSuccess) return -3;
+    if (hipEventRecord(mh->ev_r1, mh->stream) != hipSuccess) return -3;
+    mh->r1_in_flight = true;
+    const int rc = sampler_rank1_catchup(mh->st, reinterpret_cast<const int32_t*>(static_cast<char*>(mh->d_r1) + mh->r1_cap * sizeof(double)),
+                                         static_cast<const double*>(mh->d_r1), (int)n, mh->stream);
     mh->pending_gamma.clear();
-    (void)ctx;
+    mh->pending_row.clear();
+    return rc;
+}
+// the states committed since the last catch-up enter the running sums; emit_len > 0: and the refresh of
+// recomputeFullCovariance for a history of emit_len states follows in the same launch
+int mh_flush_moments(sepaihrd_mh* mh, int emit_len) {
+    if (mh->covariance_mode != SEPAIHRD_MH_COV_RUNNING) return 0;
+    const int n = mh->rows - mh->mom_rows;
+    if (n <= 0 && emit_len <= 0) return 0;
+    const int rc = sampler_moments_catchup(mh->st, mh->mom_rows, n, emit_len, mh->stream);
+    mh->mom_rows = mh->rows;
+    return rc;
+}
+// Before state `rows` is written into its ring slot: whatever is queued on the state that slot still holds runs first.
+int mh_before_commit(sepaihrd_mh* mh) {
+    const int oldest_kept = mh->rows + 1 - mh->st.window;  // after the commit the ring holds states oldest_kept .. rows
+    int rc = 0;
+    if (mh->covariance_mode == SEPAIHRD_MH_COV_RUNNING && mh->mom_rows < oldest_kept) rc = mh_flush_moments(mh, 0);
+    if (rc == 0 && !mh->pending_row.empty() && mh->pending_row.front() < oldest_kept) rc = mh_flush_rank1(mh);
     return rc;
 }
 // the adaptation step before a proposal: 0 none, 1 rank-one update, 2 + Cholesky refresh of cov + eps I, 3 + full
-// two-pass recompute first (which overwrites covariance and mean: queued rank-one updates are dropped unapplied)
+// recompute first (which overwrites covariance and mean: queued rank-one updates are dropped unapplied)
 int mh_adapt_step(sepaihrd_mh* mh, double gamma, int adapt) {
     int rc = 0;
     if (adapt >= 1) mh_queue_rank1(mh, gamma);
@@ -956,7 +995,9 @@ int mh_adapt_step(sepaihrd_mh* mh, double gamma, int adapt) {
         if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);  // :295-300
     } else if (adapt == 3) {
         mh->pending_gamma.clear();
-        rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
+        mh->pending_row.clear();
+        if (mh->covariance_mode == SEPAIHRD_MH_COV_RUNNING) rc = mh_flush_moments(mh, mh->rows);
+        else rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
         if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, mh->stream);              // :190-197, kept on success
         if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);
     }
@@ -984,27 +1025,36 @@ int mh_eval(sepaihrd_mh* mh, const double* d_theta, double* loglik, int32_t* sta
 }
 }  // namespace
 
-sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const double* x0, const double* cov0,
-                                double reg_eps, double scaling_factor) {
+sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg, const double* x0, const double* cov0) {
     if (!ctx) return nullptr;
     const int P = ctx->P;
-    if (C <= 0 || capacity <= 0 || !x0 || !cov0 || P > 200) {
-        ctx->last_error = "mh_create: need C > 0, capacity > 0, x0, cov0 and at most 200 parameters";
+    if (!cfg || cfg->chains <= 0 || cfg->iterations <= 0 || !x0 || !cov0 || P > 200 ||
+        (cfg->covariance_mode != SEPAIHRD_MH_COV_RUNNING && cfg->covariance_mode != SEPAIHRD_MH_COV_TWO_PASS)) {
+        ctx->last_error = "mh_create: need chains > 0, iterations > 0, a known covariance_mode, x0, cov0 and at most 200 parameters";
         return nullptr;
     }
+    const int C = cfg->chains;
+    const double reg_eps = cfg->reg_eps, scaling_factor = cfg->scaling_factor;
+    // ring of the newest states: every state of the run for the two-pass refresh, else the window asked for
+    // (at least 2: the newest state and the one a queued update may still read), never more than the run has
+    int window = cfg->covariance_mode == SEPAIHRD_MH_COV_TWO_PASS ? cfg->iterations
+                                                                   : std::min(cfg->iterations, std::max(cfg->adaptation_window > 0 ? cfg->adaptation_window : 128, 2));
+    const int thinning = cfg->thinning > 0 ? cfg->thinning : 0;
+    const int n_store = thinning > 0 ? (cfg->iterations - 1) / thinning + 1 : 0;
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->last_error = "hipSetDevice failed"; return nullptr; }
     const size_t CP = (size_t)C * P, CPP = CP * P;
     {
-        // the exact two-pass covariance refresh keeps every state of every chain (:168-199): say what that costs
-        // before allocating instead of failing somewhere inside
-        const double need = (double)CP * capacity * 8.0 + 2.0 * (double)CPP * 8.0 + 5.0 * (double)CP * 8.0;
+        // say what the state costs before allocating instead of failing somewhere inside
+        const double need = (double)CP * ((double)window + (double)n_store) * 8.0 + 3.0 * (double)CPP * 8.0 + 8.0 * (double)CP * 8.0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) {
-            char msg[256];
+            char msg[320];
             std::snprintf(msg, sizeof(msg),
-                          "mh_create: sampler state needs %.3f GB (history C*capacity*P = %d*%d*%d doubles, covariance + factor "
-                          "2*C*P*P) but %.3f GB of device memory are free; run fewer chains or iterations per sampler object",
-                          need / 1e9, C, capacity, P, (double)free_b / 1e9);
+                          "mh_create: sampler state needs %.3f GB (ring of newest states C*window*P = %d*%d*%d doubles, samples "
+                          "C*%d*P, covariance + factor + second moment 3*C*P*P) but %.3f GB of device memory are free; run "
+                          "fewer chains per sampler object%s",
+                          need / 1e9, C, window, P, n_store, (double)free_b / 1e9,
+                          cfg->covariance_mode == SEPAIHRD_MH_COV_TWO_PASS ? " or use SEPAIHRD_MH_COV_RUNNING (no full history)" : "");
             ctx->last_error = msg;
             return nullptr;
         }
@@ -1012,7 +1062,10 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     auto* mh = new sepaihrd_mh();
     mh->ctx = ctx;
     SamplerState& st = mh->st;
-    st.C = C; st.P = P; st.capacity = capacity; st.scaling = scaling_factor; st.reg_eps = reg_eps;
+    st.C = C; st.P = P; st.window = window; st.thinning = std::max(thinning, 1); st.n_store = n_store;
+    st.scaling = scaling_factor; st.reg_eps = reg_eps;
+    mh->covariance_mode = cfg->covariance_mode;
+    mh->iterations = cfg->iterations;
     bool ok = true;
     auto dalloc = [&](void** p, size_t bytes) {
         if (!ok) return;
@@ -1025,7 +1078,13 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     dalloc((void**)&st.chol, CPP * sizeof(double));
     dalloc((void**)&st.mean, CP * sizeof(double));
     dalloc((void**)&st.best, CP * sizeof(double));
-    dalloc((void**)&st.hist, CP * (size_t)capacity * sizeof(double));
+    dalloc((void**)&st.hist, CP * (size_t)window * sizeof(double));
+    if (n_store > 0) dalloc((void**)&st.store, CP * (size_t)n_store * sizeof(double));
+    dalloc((void**)&st.sum, CP * sizeof(double));
+    dalloc((void**)&st.wmean, CP * sizeof(double));
+    dalloc((void**)&st.m2, CPP * sizeof(double));
+    dalloc((void**)&st.accepted, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&mh->d_summary, (size_t)C * (2 * (size_t)P + 2) * sizeof(double));
     dalloc((void**)&mh->d_z, CP * sizeof(double));
     dalloc((void**)&mh->d_scale, (size_t)C * sizeof(double));
     dalloc((void**)&mh->d_loglik, (size_t)C * (sizeof(double) + sizeof(int32_t)));
@@ -1055,8 +1114,12 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     if (ok && hipStreamCreateWithFlags(&mh->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     if (ok && hipStreamCreateWithFlags(&mh->copy_stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&mh->ev_staged, hipEventDisableTiming) != hipSuccess) ok = false;
-    for (hipEvent_t* e : {&mh->ev_test_up, &mh->ev_tested, &mh->ev_fetched, &mh->ev_proposed})
+    for (hipEvent_t* e : {&mh->ev_test_up, &mh->ev_tested, &mh->ev_fetched, &mh->ev_proposed, &mh->ev_r1})
         if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false;
+    if (ok) ok = hipMemsetAsync(st.sum, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
+                 hipMemsetAsync(st.wmean, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
+                 hipMemsetAsync(st.m2, 0, CPP * sizeof(double), mh->stream) == hipSuccess &&
+                 hipMemsetAsync(st.accepted, 0, (size_t)C * sizeof(int32_t), mh->stream) == hipSuccess;
     if (ok) {
         std::vector<double> cov_all(CPP);
         for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
@@ -1069,7 +1132,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
     if (ok) ok = sampler_cholesky(st, 0.0, 1, mh->stream) == 0 && sampler_commit(st, nullptr, 0, mh->stream) == 0 &&
                  hipStreamSynchronize(mh->stream) == hipSuccess;
     if (!ok) {
-        ctx->last_error = "mh_create: device allocation or initialisation failed (history = C * capacity * P doubles)";
+        ctx->last_error = "mh_create: device allocation or initialisation failed";
         for (void* p : mh->allocs) (void)hipFree(p);
         if (mh->h_pack) (void)hipHostFree(mh->h_pack);
         if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
@@ -1077,7 +1140,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, int C, int capacity, const do
         if (mh->h_test_out) (void)hipHostFree(mh->h_test_out);
         for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
         if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
-        for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed, mh->ev_r1}) if (e) (void)hipEventDestroy(e);
         if (mh->copy_stream) (void)hipStreamDestroy(mh->copy_stream);
         if (mh->stream) (void)hipStreamDestroy(mh->stream);
         delete mh;
@@ -1100,7 +1163,7 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
         (void)hipStreamDestroy(mh->stream);
     }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
-    for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed, mh->ev_r1}) if (e) (void)hipEventDestroy(e);
     if (mh->h_pack) (void)hipHostFree(mh->h_pack);
     if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
     if (mh->h_test) (void)hipHostFree(mh->h_test);
@@ -1109,7 +1172,8 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     for (void* p : mh->allocs) (void)hipFree(p);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
     if (mh->d_gather) (void)hipFree(mh->d_gather);
-    if (mh->d_gammas) (void)hipFree(mh->d_gammas);
+    if (mh->d_r1) (void)hipFree(mh->d_r1);
+    if (mh->h_r1) (void)hipHostFree(mh->h_r1);
     delete mh;
 }
 
@@ -1162,7 +1226,7 @@ int sepaihrd_mh_step(sepaihrd_mh* mh, const uint8_t* accept, const double* scale
     if (n_patch > C) { ctx->last_error = "mh_step: more patched rows than chains"; return SEPAIHRD_E_INVALID_ARG; }
     for (int k = 0; k < n_patch; ++k)
         if (patch_chain[k] < 0 || patch_chain[k] >= C) { ctx->last_error = "mh_step: patched chain out of range"; return SEPAIHRD_E_INVALID_ARG; }
-    if (accept && mh->rows >= mh->st.capacity) { ctx->last_error = "mh_step: history capacity exhausted"; return SEPAIHRD_E_INVALID_ARG; }
+    if (accept && mh->rows >= mh->iterations) { ctx->last_error = "mh_step: more states than the sampler was created for"; return SEPAIHRD_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     hipStream_t st = mh->stream;
     // one upload: [accept C | scale C | chains n | rows n x P]
@@ -1179,7 +1243,8 @@ int sepaihrd_mh_step(sepaihrd_mh* mh, const uint8_t* accept, const double* scale
     HIP_TRY(hipMemcpyAsync(mh->d_pack, mh->h_pack, used, hipMemcpyHostToDevice, st), ctx, return SEPAIHRD_E_HIP);
     int rc = 0;
     if (accept) {
-        rc = sampler_commit(mh->st, mh->d_pack, mh->rows, st);
+        rc = mh_before_commit(mh);
+        if (rc == 0) rc = sampler_commit(mh->st, mh->d_pack, mh->rows, st);
         if (rc == 0) mh->rows++;
     }
     if (rc == 0) rc = mh_adapt_step(mh, gamma, adapt);
@@ -1221,7 +1286,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     if (!mh->values_set) { ctx->last_error = "mh_step_tested: call sepaihrd_mh_set_values first"; return SEPAIHRD_E_INVALID_ARG; }
     if (mh->test_pending) { ctx->last_error = "mh_step_tested: the previous test has not been fetched"; return SEPAIHRD_E_INVALID_ARG; }
     if (!last && !mh->staged) { ctx->last_error = "mh_step_tested: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
-    if (mh->rows >= mh->st.capacity) { ctx->last_error = "mh_step_tested: history capacity exhausted"; return SEPAIHRD_E_INVALID_ARG; }
+    if (mh->rows >= mh->iterations) { ctx->last_error = "mh_step_tested: more states than the sampler was created for"; return SEPAIHRD_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     hipStream_t st = mh->stream, cs = mh->copy_stream;
     const size_t CP = (size_t)C * P;
@@ -1234,6 +1299,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     HIP_TRY(hipStreamWaitEvent(st, mh->ev_test_up, 0), ctx, return SEPAIHRD_E_HIP);
     double* const d_values = static_cast<double*>(mh->d_test_out);
     uint8_t* const d_flags = reinterpret_cast<uint8_t*>(d_values + C);
+    if (mh_before_commit(mh) != 0) { ctx->last_error = "mh_step_tested: catch-up of the queued updates failed"; return SEPAIHRD_E_HIP; }
     if (!last && adapt <= 1) {
         // no covariance refresh between commit and proposal: test, commit and proposal in one launch
         // (the staged normals landed before the test's inputs: same copy stream, staged first -- ev_test_up covers them)
@@ -1257,7 +1323,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
         mh->staged = false;
         return sepaihrd_eval_batch_device(ctx, mh->st.prop, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, st);
     }
-    int rc = sampler_accept_test(C, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C, mh->d_lp,
+    int rc = sampler_accept_test(mh->st, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C, mh->d_lp,
                                  mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, st);
     if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);
@@ -1267,7 +1333,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
             return SEPAIHRD_E_HIP);
     HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
     mh->test_pending = true;
-    rc = sampler_commit(mh->st, d_flags, mh->rows, st);
+    rc = sampler_commit_counted(mh->st, d_flags, mh->rows, 1, st);
     if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
     mh->rows++;
     if (last) return SEPAIHRD_OK;
@@ -1300,11 +1366,12 @@ int sepaihrd_mh_fetch_test(sepaihrd_mh* mh, double* values, uint8_t* flags) {
 int sepaihrd_mh_commit(sepaihrd_mh* mh, const uint8_t* accept) {
     if (!mh || !accept) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
-    if (mh->rows >= mh->st.capacity) {
-        ctx->last_error = "mh_commit: history capacity exhausted";
+    if (mh->rows >= mh->iterations) {
+        ctx->last_error = "mh_commit: more states than the sampler was created for";
         return SEPAIHRD_E_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (mh_before_commit(mh) != 0) { ctx->last_error = "mh_commit: catch-up of the queued updates failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipMemcpyAsync(mh->d_accept, accept, (size_t)mh->st.C, hipMemcpyHostToDevice, mh->stream), ctx, return SEPAIHRD_E_HIP);
     if (sampler_commit(mh->st, mh->d_accept, mh->rows, mh->stream) != 0) {
         ctx->last_error = "mh_commit: launch failed";
@@ -1330,19 +1397,77 @@ int sepaihrd_mh_read_history(sepaihrd_mh* mh, const int32_t* rows, int n_rows, d
     if (!mh || !rows || n_rows <= 0 || !out) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
-    const int C = mh->st.C, P = mh->st.P;
+    const int C = mh->st.C, P = mh->st.P, W = mh->st.window;
     for (int r = 0; r < n_rows; ++r)
-        if (rows[r] < 0 || rows[r] >= mh->rows) {
-            ctx->last_error = "mh_read_history: row out of range";
+        if (rows[r] < 0 || rows[r] >= mh->rows || rows[r] < mh->rows - W) {
+            ctx->last_error = "mh_read_history: state not committed yet, or no longer among the newest `window` states "
+                              "(the thinned samples are read with sepaihrd_mh_read_samples)";
             return SEPAIHRD_E_INVALID_ARG;
         }
     HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
-    // strided copies straight out of the history: row r of every chain = a 2-D region
+    // strided copies straight out of the ring: state r of every chain = a 2-D region
     for (int r = 0; r < n_rows; ++r)
         HIP_TRY(hipMemcpy2D(out + (size_t)r * P, (size_t)n_rows * P * sizeof(double),
-                            mh->st.hist + (size_t)rows[r] * P, (size_t)mh->st.capacity * P * sizeof(double),
+                            mh->st.hist + (size_t)(rows[r] % W) * P, (size_t)W * P * sizeof(double),
                             (size_t)P * sizeof(double), (size_t)C, hipMemcpyDeviceToHost),
                 ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_sample_count(const sepaihrd_mh* mh) {
+    if (!mh || mh->st.n_store <= 0 || mh->rows <= 0) return 0;
+    return std::min(mh->st.n_store, (mh->rows - 1) / mh->st.thinning + 1);
+}
+
+int sepaihrd_mh_read_samples(sepaihrd_mh* mh, int first, int count, double* out) {
+    if (!mh || !out || first < 0 || count <= 0) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (first + count > sepaihrd_mh_sample_count(mh)) {
+        ctx->last_error = "mh_read_samples: beyond the samples stored so far";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    const size_t P = (size_t)mh->st.P;
+    HIP_TRY(hipMemcpy2D(out, (size_t)count * P * sizeof(double), mh->st.store + (size_t)first * P,
+                        (size_t)mh->st.n_store * P * sizeof(double), (size_t)count * P * sizeof(double), (size_t)mh->st.C,
+                        hipMemcpyDeviceToHost),
+            ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_summary_records(sepaihrd_mh* mh, int first_sample, double* out, double* d_out) {
+    if (!mh || (!out && !d_out)) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    const int ns = sepaihrd_mh_sample_count(mh);
+    if (first_sample < 0 || first_sample >= ns) {
+        ctx->last_error = "mh_summary_records: first_sample beyond the samples stored so far";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    if (!mh->values_set) { ctx->last_error = "mh_summary_records: the chains' values are unknown (sepaihrd_mh_set_values)"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    double* const dst = d_out ? d_out : mh->d_summary;
+    if (sampler_summary_records(mh->st, mh->d_best_lp, first_sample, ns, dst, mh->stream) != 0) {
+        ctx->last_error = "mh_summary_records: launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    if (out)
+        HIP_TRY(hipMemcpy(out, dst, (size_t)mh->st.C * (2 * (size_t)mh->st.P + 2) * sizeof(double), hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_moments(sepaihrd_mh* mh, double* mean, double* m2) {
+    if (!mh || (!mean && !m2)) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (mh->covariance_mode != SEPAIHRD_MH_COV_RUNNING) { ctx->last_error = "mh_read_moments: the sampler keeps no running sums (two-pass mode)"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (mh_flush_moments(mh, 0) != 0) { ctx->last_error = "mh_read_moments: catch-up failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    const size_t CP = (size_t)mh->st.C * mh->st.P;
+    if (mean) HIP_TRY(hipMemcpy(mean, mh->st.wmean, CP * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (m2) HIP_TRY(hipMemcpy(m2, mh->st.m2, CP * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
 }
 

@@ -159,22 +159,36 @@ inline size_t eval_lds_bytes(const DevProblem& pb) {
 }
 
 // ---- Adaptive-Metropolis state of C chains resident in HBM (csrc/sepaihrd_sampler.hip) ----
+// chain_history_ of the reference (MetropolisHastingsSampler.cpp:262-264,354) is read in three places only: its newest
+// state by updateCovarianceRank1 (:157), all of it by recomputeFullCovariance (:168-199), every thinning-th state as the
+// run's samples (:357-360).  Kept here: a RING of the last `window` states (pending rank-one and co-moment updates read
+// it), the running sums that make the refresh O(P^2) (oracle::RunningMoments states the recurrence), and the thinned
+// samples.  With covariance_mode two-pass the ring holds every state (window = rows of the whole run) and the refresh
+// walks it as the reference does.
 struct SamplerState {
-    int32_t C, P, capacity;   // chains, parameters, history rows allocated per chain
+    int32_t C, P;
+    int32_t window;           // rows of the ring per chain; state r lives in slot r % window
+    int32_t thinning, n_store;  // states r with r % thinning == 0 are also kept as sample r / thinning (n_store = 0: none)
     double scaling, reg_eps;  // 2.38^2 / P and the regularisation epsilon of the covariance refresh
     double* x;      // [C][P] current state
     double* prop;   // [C][P] last proposal (after applyConstraints)
     double* cov;    // [C][P][P] proposal covariance, row-major
     double* chol;   // [C] x (P P allocated) its lower Cholesky factor, the lower triangle column by column: L(i, j), i >= j, at j P - j (j - 1) / 2 + (i - j)
-    double* mean;   // [C][P] running mean
-    double* hist;   // [C][capacity][P] every state of every chain
+    double* mean;   // [C][P] running mean (running_mean_)
+    double* hist;   // [C][window][P] ring of the newest states
     double* best;   // [C][P] the best state so far (updated by commit where bit 1 of the chain's accept byte is set)
+    double* store;  // [C][n_store][P] the thinned samples
+    double* sum;    // [C][P] running sum of all states, in the order of the reference's mean loop (:171-174)
+    double* wmean;  // [C][P] Welford mean of all states
+    double* m2;     // [C][P][P] centred second moment, entries j <= i
+    int32_t* accepted;  // [C] accepted proposals so far
 };
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
+int sampler_commit_counted(const SamplerState& s, const uint8_t* d_accept, int row, int accepted_known, void* stream);
 // the accept test on the device (flags: bit 0 accepted, bit 1 best so far, bit 2 no uniform drawn) and the proposal that
 // follows it with the normals of the continuation taken
-int sampler_accept_test(int C, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+int sampler_accept_test(const SamplerState& s, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
                         const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
                         double* d_values, void* stream);
 // the three in one launch (block = chain), for iterations without a covariance refresh between commit and proposal
@@ -185,9 +199,16 @@ int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, con
 int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,
                            const uint8_t* d_flags, const double* d_scale, void* stream);
 int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_rows, int n_patch, int P, void* stream);
-int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream);
-int sampler_rank1_catchup(const SamplerState& s, const double* d_gammas, int row0, int n, void* stream);
+// n queued rank-one updates (:154-166) in order: update k reads state d_rows[k] (still in the ring) with d_gammas[k]
+int sampler_rank1_catchup(const SamplerState& s, const int32_t* d_rows, const double* d_gammas, int n, void* stream);
+// states row0 .. row0 + n - 1 (still in the ring; they are states number row0 + 1 .. of the chain) enter the running
+// sums; emit_len > 0: then running mean and covariance of a history of emit_len states are written (:175-190)
+int sampler_moments_catchup(const SamplerState& s, int row0, int n, int emit_len, void* stream);
+// recomputeFullCovariance as the reference writes it, two passes over states 0 .. len - 1 (the ring must hold them all)
 int sampler_full_covariance(const SamplerState& s, int len, void* stream);
 int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream);
+// per-chain summary record of SURVEY 8(e): [P means | P variances (n - 1) | best value | accepted proposals] over the
+// stored samples first_sample .. n_samples - 1, written to d_out [C][2 P + 2]
+int sampler_summary_records(const SamplerState& s, const double* d_best_lp, int first_sample, int n_samples, double* d_out, void* stream);
 
 }  // namespace sepaihrd

@@ -9,16 +9,20 @@
 // doubles of history, which belongs next to the likelihood kernel, not on the host.
 //
 // What stays on the host: the random streams (std::mt19937 + libstdc++ distributions, whose draw
-// order depends on the accept test), the accept decision and the scalar scale adaptation.
+// order depends on the accept test) and the scalar scale adaptation.
 // What lives here (one launch each, all chains):
 //   propose   prop = applyConstraints(x + scale * L z)                      (:91-102,309)
-//   commit    x <- prop where accepted, history append                      (:332-340,371)
-//   rank-one  cov <- (1-g) cov + g d d^T, mean <- mean + g d, d = x_new - mean   (:154-166)
-//   full      two-pass sample covariance over the history, scaled + epsilon (:168-199)
+//   test      accept when log_ratio >= 0 or log(u) < log_ratio              (:318-331)
+//   commit    x <- prop where accepted; the state goes to the ring of the newest states and,
+//             every thinning-th one, to the sample store                    (:332-340,354-360)
+//   rank-one  cov <- (1-g) cov + g d d^T, mean <- mean + g d, d = x_new - mean   (:154-166), queued
+//   moments   running sum / Welford mean / centred second moment of every state (oracle::RunningMoments):
+//             the covariance refresh (:168-199) costs O(P^2) whatever the length of the chain
+//   two-pass  the same refresh as the reference writes it, over a ring that holds the whole history
 //   cholesky  lower factor, kept only when the matrix is positive definite  (:240-246,295-300)
-// Every sum runs in the reference's order (history rows ascending, k ascending in the Cholesky
-// recurrences) and this file is compiled with -ffp-contract=off, so the numbers are those of the
-// host loop bit for bit (tests compare accept traces, samples and covariances with it).
+// Every sum runs in a fixed order (states ascending, k ascending in the Cholesky recurrences) and this
+// file is compiled with -ffp-contract=off, so the numbers are those of the host loop and of the oracle
+// bit for bit (tests compare accept traces, samples and covariances).
 // =============================================================================
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -49,6 +53,15 @@ __device__ __forceinline__ double constrain(double v, double lo, double hi, int 
     }
     if (mode == 0) return (0.0 < v) ? v : 0.0;
     return fabs(v);
+}
+
+// where state `row` of chain c lives: its ring slot, and its place in the sample store (nullptr: not a stored state)
+__device__ __forceinline__ double* ring_row(const SamplerState& s, const int c, const int row) {
+    return s.hist + ((size_t)c * s.window + (size_t)(row % s.window)) * s.P;
+}
+__device__ __forceinline__ double* store_row(const SamplerState& s, const int c, const int row) {
+    if (s.n_store <= 0 || row % s.thinning != 0 || row / s.thinning >= s.n_store) return nullptr;
+    return s.store + ((size_t)c * s.n_store + (size_t)(row / s.thinning)) * s.P;
 }
 
 // prop_i = constrain(x_i + scale * sum_{j <= i} L_ij z_j), j ascending
@@ -99,7 +112,7 @@ __global__ void mh_propose_kernel(const SamplerState s, const DevProblem pb, con
 __global__ void mh_accept_kernel(const int C, const double* __restrict__ loglik, const int32_t* __restrict__ status,
                                  const double* __restrict__ log_u, const double* __restrict__ scale_reject,
                                  const double* __restrict__ scale_accept, double* lp, double* best_lp, double* scale_sel,
-                                 uint8_t* flags, double* values) {
+                                 uint8_t* flags, double* values, int32_t* accepted) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double v = loglik[c];
@@ -110,6 +123,7 @@ __global__ void mh_accept_kernel(const int C, const double* __restrict__ loglik,
     uint8_t f = (acc ? 1 : 0) | (no_uniform ? 4 : 0);
     if (acc) {
         lp[c] = v;
+        accepted[c] += 1;
         if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
     }
     flags[c] = f;
@@ -153,6 +167,7 @@ __global__ __launch_bounds__(WAVE) void mh_test_commit_propose_kernel(const Samp
         int f = (acc ? 1 : 0) | (no_uniform ? 4 : 0);
         if (acc) {
             lp[c] = v;
+            s.accepted[c] += 1;
             if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
         }
         const double sc = acc ? scale_accept[c] : scale_reject[c];
@@ -165,12 +180,15 @@ __global__ __launch_bounds__(WAVE) void mh_test_commit_propose_kernel(const Samp
     __syncthreads();
     const int f = f_sh;
     const double sc = sc_sh;
+    double* const ring = ring_row(s, c, row);
+    double* const kept = store_row(s, c, row);
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         const size_t idx = (size_t)c * P + i;
         double v = s.x[idx];
         if (f & 1) { v = s.prop[idx]; s.x[idx] = v; }
         if (f & 2) s.best[idx] = s.prop[idx];
-        s.hist[((size_t)c * s.capacity + row) * P + i] = v;
+        ring[i] = v;
+        if (kept) kept[i] = v;
         xs[i] = v;
     }
     __syncthreads();
@@ -183,70 +201,146 @@ __global__ __launch_bounds__(WAVE) void mh_test_commit_propose_kernel(const Samp
     }
 }
 
-__global__ void mh_commit_kernel(const SamplerState s, const uint8_t* accept, const int row) {
+// accepted_known: the accept byte comes from mh_accept_kernel, which has counted it already
+__global__ void mh_commit_kernel(const SamplerState s, const uint8_t* accept, const int row, const int accepted_known) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)s.C * s.P) return;
     const int c = (int)(idx / s.P), i = (int)(idx % s.P);
     double v = s.x[idx];
     // accept byte: bit 0 = the proposal was accepted, bit 1 = it is the chain's best state so far (caller's bookkeeping)
-    if (accept != nullptr && (accept[c] & 1)) { v = s.prop[idx]; s.x[idx] = v; }
+    if (accept != nullptr && (accept[c] & 1)) {
+        v = s.prop[idx];
+        s.x[idx] = v;
+        if (i == 0 && !accepted_known) s.accepted[c] += 1;
+    }
     if (accept != nullptr && (accept[c] & 2)) s.best[idx] = s.prop[idx];
-    s.hist[((size_t)c * s.capacity + row) * s.P + i] = v;
+    ring_row(s, c, row)[i] = v;
+    double* const kept = store_row(s, c, row);
+    if (kept) kept[i] = v;
 }
 
-// rank-one update, covariance part; d uses the mean BEFORE this iteration's update
-__global__ void mh_rank1_cov_kernel(const SamplerState s, const double gamma, const int last_row) {
+// The rank-one updates of updateCovarianceRank1 (:154-166), n of them in one launch: update k reads state rows[k]
+// with gammas[k], in order; d uses the mean BEFORE that update.  The reference performs one per iteration (:286-288)
+// but reads the result only at a refresh that does not recompute from the history (fewer than P + 10 states) and at
+// the end of the run -- every recompute overwrites covariance AND mean -- so the library queues the updates and runs
+// them when (if) someone looks: one pass over the C P^2 covariances per READ instead of per iteration (252 MB of
+// traffic at 4096 chains x 62 parameters).  Each thread replays the mean recurrence of its i and j next to its
+// covariance entry: the operations and their order are those of one update per iteration, so the bits are the same.
+__global__ void mh_rank1_catchup_cov_kernel(const SamplerState s, const int32_t* rows, const double* gammas, const int n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t PP = (size_t)s.P * s.P;
     if (idx >= (size_t)s.C * PP) return;
     const int c = (int)(idx / PP);
     const int i = (int)((idx % PP) / s.P), j = (int)(idx % s.P);
-    const double* ns = s.hist + ((size_t)c * s.capacity + last_row) * s.P;
-    const double* m = s.mean + (size_t)c * s.P;
-    const double di = ns[i] - m[i], dj = ns[j] - m[j];
-    s.cov[idx] = (1.0 - gamma) * s.cov[idx] + gamma * (di * dj);
-}
-__global__ void mh_rank1_mean_kernel(const SamplerState s, const double gamma, const int last_row) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)s.C * s.P) return;
-    const int c = (int)(idx / s.P), i = (int)(idx % s.P);
-    const double d = s.hist[((size_t)c * s.capacity + last_row) * s.P + i] - s.mean[idx];
-    s.mean[idx] += gamma * d;
-}
-
-// The same rank-one updates applied LATER, n of them in one launch: rows row0 .. row0 + n - 1 with their own gammas,
-// in order.  The reference performs one per iteration (:286-288) but reads the result only at a refresh that does
-// not recompute from the history (fewer than P + 10 states) and at the end of the run -- every recompute overwrites
-// covariance AND mean -- so the library queues the updates and runs them when (if) someone looks: one pass over the
-// C P^2 covariances per READ instead of per iteration (252 MB of traffic at 4096 chains x 62 parameters).  Each thread
-// replays the mean recurrence of its i and j next to its covariance entry: the operations and their order are those
-// of the per-iteration kernels above, so the bits are the same.
-__global__ void mh_rank1_catchup_cov_kernel(const SamplerState s, const double* gammas, const int row0, const int n) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t PP = (size_t)s.P * s.P;
-    if (idx >= (size_t)s.C * PP) return;
-    const int c = (int)(idx / PP);
-    const int i = (int)((idx % PP) / s.P), j = (int)(idx % s.P);
-    const double* h = s.hist + ((size_t)c * s.capacity + row0) * s.P;
     double mi = s.mean[(size_t)c * s.P + i], mj = s.mean[(size_t)c * s.P + j];
     double cov = s.cov[idx];
     for (int r = 0; r < n; ++r) {
         const double g = gammas[r];
-        const double di = h[(size_t)r * s.P + i] - mi, dj = h[(size_t)r * s.P + j] - mj;
+        const double* h = ring_row(s, c, rows[r]);
+        const double di = h[i] - mi, dj = h[j] - mj;
         cov = (1.0 - g) * cov + g * (di * dj);
         mi += g * di;
         mj += g * dj;
     }
     s.cov[idx] = cov;
 }
-__global__ void mh_rank1_catchup_mean_kernel(const SamplerState s, const double* gammas, const int row0, const int n) {
+__global__ void mh_rank1_catchup_mean_kernel(const SamplerState s, const int32_t* rows, const double* gammas, const int n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)s.C * s.P) return;
     const int c = (int)(idx / s.P), i = (int)(idx % s.P);
-    const double* h = s.hist + ((size_t)c * s.capacity + row0) * s.P + i;
     double m = s.mean[idx];
-    for (int r = 0; r < n; ++r) m += gammas[r] * (h[(size_t)r * s.P] - m);
+    for (int r = 0; r < n; ++r) m += gammas[r] * (ring_row(s, c, rows[r])[i] - m);
     s.mean[idx] = m;
+}
+
+// States row0 .. row0 + n - 1 of every chain enter its running sums (oracle::RunningMoments::push, one state after
+// the other): state r is the (r + 1)-th, so  rn = 1 / (r + 1),  w = r / (r + 1),  d = x - wmean,
+//     m2_ij += w * (d_i * d_j)  (j <= i),   wmean_i += d_i * rn,   sum_i += x_i.
+// One workgroup per chain.  The deviations d of a chunk of states are formed first -- thread i walks the chunk with
+// its own mean recurrence, the only sequential part -- and parked in LDS; then every thread adds the chunk to its
+// entries of m2, states ascending.  emit_len > 0: the refresh of recomputeFullCovariance (:175-190) for a history of
+// emit_len states follows at once: running mean = sum / len (the reference's own mean, same additions in the same
+// order) and cov_ij = scaling * (m2_ij / (len - 1)) + eps [i == j], both triangles written.
+constexpr int MOMENT_THREADS = 256;
+__global__ __launch_bounds__(MOMENT_THREADS) void mh_moments_catchup_kernel(const SamplerState s, const int row0, const int n,
+                                                                            const int chunk_rows, const int emit_len) {
+    extern __shared__ double dev[];  // [chunk_rows][P] deviations, then [chunk_rows] weights w
+    const int c = blockIdx.x, P = s.P, tid = threadIdx.x;
+    double* const wts = dev + (size_t)chunk_rows * P;
+    double* const m2 = s.m2 + (size_t)c * P * P;
+    for (int base = 0; base < n; base += chunk_rows) {
+        const int rows = min(chunk_rows, n - base);
+        for (int i = tid; i < P; i += MOMENT_THREADS) {
+            double mean = s.wmean[(size_t)c * P + i], sum = s.sum[(size_t)c * P + i];
+            for (int r = 0; r < rows; ++r) {
+                const int row = row0 + base + r;
+                const double x = ring_row(s, c, row)[i];
+                const double rn = 1.0 / (double)(row + 1);
+                const double d = x - mean;
+                dev[(size_t)r * P + i] = d;
+                mean += d * rn;
+                sum += x;
+            }
+            s.wmean[(size_t)c * P + i] = mean;
+            s.sum[(size_t)c * P + i] = sum;
+        }
+        for (int r = tid; r < rows; r += MOMENT_THREADS) wts[r] = (double)(row0 + base + r) / (double)(row0 + base + r + 1);
+        __syncthreads();
+        const bool emit = emit_len > 0 && base + rows >= n;
+        const double denom = (double)(emit_len - 1);
+        for (int e = tid; e < P * P; e += MOMENT_THREADS) {
+            const int i = e / P, j = e - i * P;
+            if (j > i) continue;
+            double acc = m2[e];
+            for (int r = 0; r < rows; ++r) acc += wts[r] * (dev[(size_t)r * P + i] * dev[(size_t)r * P + j]);
+            m2[e] = acc;
+            if (emit) {
+                const double v = s.scaling * (acc / denom) + (i == j ? s.reg_eps : 0.0);
+                s.cov[((size_t)c * P + i) * P + j] = v;
+                s.cov[((size_t)c * P + j) * P + i] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (emit_len > 0) {
+        if (n <= 0) {  // nothing was pending: the refresh alone
+            const double denom = (double)(emit_len - 1);
+            for (int e = tid; e < P * P; e += MOMENT_THREADS) {
+                const int i = e / P, j = e - i * P;
+                if (j > i) continue;
+                const double v = s.scaling * (m2[e] / denom) + (i == j ? s.reg_eps : 0.0);
+                s.cov[((size_t)c * P + i) * P + j] = v;
+                s.cov[((size_t)c * P + j) * P + i] = v;
+            }
+        }
+        for (int i = tid; i < P; i += MOMENT_THREADS) s.mean[(size_t)c * P + i] = s.sum[(size_t)c * P + i] / (double)emit_len;
+    }
+}
+
+// SURVEY 8(e)'s per-chain summary record from the sample store: mean_i = (sum_s x_si) / S and the unbiased variance
+// sum_s (x_si - mean_i)^2 / (S - 1) over samples first .. n_samples - 1 (two passes, samples ascending), the chain's best
+// value and its accepted proposals.  Thread = (chain, parameter).
+__global__ void mh_summary_kernel(const SamplerState s, const double* __restrict__ best_lp, const int first, const int n_samples, double* out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)s.C * s.P) return;
+    const int c = (int)(idx / s.P), i = (int)(idx % s.P);
+    const int W = 2 * s.P + 2;
+    const double* col = s.store + ((size_t)c * s.n_store + first) * s.P + i;
+    const int S = n_samples - first;
+    double sum = 0.0;
+    for (int k = 0; k < S; ++k) sum += col[(size_t)k * s.P];
+    const double mean = sum / (double)S;
+    double ss = 0.0;
+    for (int k = 0; k < S; ++k) {
+        const double d = col[(size_t)k * s.P] - mean;
+        ss += d * d;
+    }
+    out[(size_t)c * W + i] = mean;
+    out[(size_t)c * W + s.P + i] = S > 1 ? ss / (double)(S - 1) : 0.0;
+    if (i == 0) {
+        out[(size_t)c * W + 2 * s.P] = best_lp[c];
+        out[(size_t)c * W + 2 * s.P + 1] = (double)s.accepted[c];
+    }
 }
 
 // pass 1 of recomputeFullCovariance: mean_i = (sum_s h[s][i]) / len, s ascending
@@ -254,7 +348,7 @@ __global__ void mh_full_mean_kernel(const SamplerState s, const int len) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)s.C * s.P) return;
     const int c = (int)(idx / s.P), i = (int)(idx % s.P);
-    const double* h = s.hist + (size_t)c * s.capacity * s.P + i;
+    const double* h = s.hist + (size_t)c * s.window * s.P + i;
     double m = 0.0;
     for (int r = 0; r < len; ++r) m += h[(size_t)r * s.P];
     s.mean[idx] = m / (double)len;
@@ -270,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void mh_full_cov_kernel(const SamplerState s,
     const int j = blockIdx.z * WAVE + threadIdx.x;
     const int P = s.P;
     const bool live = j < P;
-    const double* h = s.hist + (size_t)c * s.capacity * P;
+    const double* h = s.hist + (size_t)c * s.window * P;
     const double* m = s.mean + (size_t)c * P;
     const double mj = live ? m[j] : 0.0;
     double mi[IT], acc[IT];
@@ -353,11 +447,11 @@ int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_r
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int sampler_accept_test(int C, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+int sampler_accept_test(const SamplerState& s, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
                         const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
                         double* d_values, void* stream) {
-    hipLaunchKernelGGL(mh_accept_kernel, dim3(blocks_for((size_t)C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C, d_loglik,
-                       d_status, d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values);
+    hipLaunchKernelGGL(mh_accept_kernel, dim3(blocks_for((size_t)s.C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), s.C, d_loglik,
+                       d_status, d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values, s.accepted);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,
@@ -377,24 +471,43 @@ int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, con
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// d_accept written by sampler_accept_test (flags) has been counted there; a caller's own accept bytes are counted here
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream) {
+    return sampler_commit_counted(s, d_accept, row, 0, stream);
+}
+int sampler_commit_counted(const SamplerState& s, const uint8_t* d_accept, int row, int accepted_known, void* stream) {
     hipLaunchKernelGGL(mh_commit_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       s, d_accept, row);
+                       s, d_accept, row, accepted_known);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int sampler_rank1(const SamplerState& s, double gamma, int last_row, void* stream) {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mh_rank1_cov_kernel, dim3(blocks_for((size_t)s.C * s.P * s.P, 256)), dim3(256), 0, st, s, gamma, last_row);
-    hipLaunchKernelGGL(mh_rank1_mean_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, st, s, gamma, last_row);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-int sampler_rank1_catchup(const SamplerState& s, const double* d_gammas, int row0, int n, void* stream) {
+int sampler_rank1_catchup(const SamplerState& s, const int32_t* d_rows, const double* d_gammas, int n, void* stream) {
     if (n <= 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mh_rank1_catchup_cov_kernel, dim3(blocks_for((size_t)s.C * s.P * s.P, 256)), dim3(256), 0, st, s, d_gammas, row0, n);
-    hipLaunchKernelGGL(mh_rank1_catchup_mean_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, st, s, d_gammas, row0, n);
+    hipLaunchKernelGGL(mh_rank1_catchup_cov_kernel, dim3(blocks_for((size_t)s.C * s.P * s.P, 256)), dim3(256), 0, st, s, d_rows, d_gammas, n);
+    hipLaunchKernelGGL(mh_rank1_catchup_mean_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, st, s, d_rows, d_gammas, n);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_moments_catchup(const SamplerState& s, int row0, int n, int emit_len, void* stream) {
+    if (n <= 0 && emit_len <= 0) return 0;
+    // deviations of a chunk of states in LDS: up to 64 KiB of the 160 KiB (P <= 200: at least 40 states per chunk)
+    int chunk = (int)((64 * 1024) / ((size_t)(s.P + 1) * sizeof(double)));
+    if (chunk > n) chunk = n > 0 ? n : 1;
+    const size_t lds = (size_t)chunk * (s.P + 1) * sizeof(double);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mh_moments_catchup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * 1024) != hipSuccess)
+        return -3;
+    hipLaunchKernelGGL(mh_moments_catchup_kernel, dim3(s.C), dim3(MOMENT_THREADS), lds, static_cast<hipStream_t>(stream), s, row0, n,
+                       chunk, emit_len);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_summary_records(const SamplerState& s, const double* d_best_lp, int first_sample, int n_samples, double* d_out, void* stream) {
+    if (s.n_store <= 0 || first_sample < 0 || n_samples > s.n_store || first_sample >= n_samples) return -1;
+    hipLaunchKernelGGL(mh_summary_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), s,
+                       d_best_lp, first_sample, n_samples, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -17,7 +17,7 @@ from .problem import SEPAIHRDProblem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsepaihrd_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 LOWEST = -np.finfo(np.float64).max
 
 _dp = C.POINTER(C.c_double)
@@ -54,6 +54,28 @@ class sepaihrd_kernel_info(C.Structure):
 
 
 # every symbol include/sepaihrd_hip.h declares
+class sepaihrd_mh_config(C.Structure):
+    """include/sepaihrd_hip.h: struct sepaihrd_mh_config"""
+    _fields_ = [("chains", C.c_int32), ("iterations", C.c_int32), ("thinning", C.c_int32),
+                ("adaptation_window", C.c_int32), ("covariance_mode", C.c_int32), ("reserved", C.c_int32),
+                ("reg_eps", C.c_double), ("scaling_factor", C.c_double)]
+
+
+MH_COV_RUNNING, MH_COV_TWO_PASS = 0, 1
+
+
+def mh_create(lib, ctx, chains: int, iterations: int, x0: np.ndarray, cov0: np.ndarray, reg_eps: float = 1e-6,
+              scaling_factor: Optional[float] = None, thinning: int = 1, adaptation_window: int = 0,
+              covariance_mode: int = MH_COV_RUNNING):
+    """sepaihrd_mh_create with its config struct filled; returns the opaque sampler handle (None on failure)."""
+    P = x0.shape[-1]
+    cfg = sepaihrd_mh_config(chains, iterations, thinning, adaptation_window, covariance_mode, 0, reg_eps,
+                             scaling_factor if scaling_factor is not None else 2.38 * 2.38 / P)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    cov0 = np.ascontiguousarray(cov0, dtype=np.float64)
+    return lib.sepaihrd_mh_create(ctx, C.byref(cfg), x0.ctypes.data, cov0.ctypes.data)
+
+
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
     "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_set_precision", "sepaihrd_eval_batch",
@@ -63,6 +85,7 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_mh_propose", "sepaihrd_mh_fetch", "sepaihrd_mh_stage_normals", "sepaihrd_mh_staging_buffer", "sepaihrd_mh_step", "sepaihrd_mh_read_best", "sepaihrd_mh_busy", "sepaihrd_mh_set_values", "sepaihrd_mh_test_buffer",
     "sepaihrd_mh_step_tested", "sepaihrd_mh_fetch_test", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
     "sepaihrd_mh_read_covariance", "sepaihrd_mh_read_proposal", "sepaihrd_mh_history_length",
+    "sepaihrd_mh_sample_count", "sepaihrd_mh_read_samples", "sepaihrd_mh_read_moments", "sepaihrd_mh_summary_records",
 )
 
 _lib = None
@@ -109,7 +132,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_set_timing.argtypes = [vp, C.c_int]
     lib.sepaihrd_get_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.sepaihrd_mh_create.restype = vp
-    lib.sepaihrd_mh_create.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double]
+    lib.sepaihrd_mh_create.argtypes = [vp, C.POINTER(sepaihrd_mh_config), vp, vp]
+    lib.sepaihrd_mh_sample_count.argtypes = [vp]
+    lib.sepaihrd_mh_read_samples.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.sepaihrd_mh_read_moments.argtypes = [vp, vp, vp]
+    lib.sepaihrd_mh_summary_records.argtypes = [vp, C.c_int, vp, vp]
     lib.sepaihrd_mh_destroy.restype = None
     lib.sepaihrd_mh_destroy.argtypes = [vp]
     lib.sepaihrd_mh_evaluate_current.argtypes = [vp, vp, vp]

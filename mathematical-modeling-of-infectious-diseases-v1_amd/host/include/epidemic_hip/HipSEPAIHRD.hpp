@@ -247,6 +247,10 @@ public:
                                                                 const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives,
                                                                 IParameterManager& parameterManager);
     void setHostThreads(int n) { host_threads_ = n; }  // per-run cap on the OpenMP team (0 = the CPU share)
+    // recomputeFullCovariance (MetropolisHastingsSampler.cpp:168-199) as the reference writes it -- two passes over the
+    // whole chain history, O(t P^2) per refresh and every state kept -- instead of the running co-moments the sampler
+    // carries by default (O(P^2) per refresh, no history; same running mean bit for bit, covariance equal to ~1e-13)
+    void setTwoPassCovariance(bool on) { two_pass_covariance_ = on; }
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
     // wall time of the iteration loop of the last device-resident run (proposal 1 staged .. last accept test), without
     // the set-up before it (history allocation, initial values) and the read-back after it; groups: the slowest group
@@ -263,6 +267,8 @@ private:
     std::vector<std::vector<unsigned char>> traces_;
     std::vector<double> initial_cov_;  // row-major P x P, empty = none
     int host_threads_ = 0;
+    bool two_pass_covariance_ = false;
+    int adaptation_window_ = 0;  // ring of newest states on the device (0: adaptation period + 1, at least 128)
     double last_loop_seconds_ = 0.0;
 };
 

@@ -31,8 +31,23 @@ struct MultiChainMetropolisHastings::Chain {
     double lp = 0.0, log_scale = 0.0, scale = 1.0;
     std::deque<int> recent;
     int emergency = 0, accepted = 0;
-    std::vector<double> history;  // (t+1) x P, every state of the chain (covariance re-estimation)
+    std::vector<double> history;  // chain_history_: every state ((t+1) x P) for the two-pass refresh, else the newest only
     size_t history_len = 0;
+    // recomputeFullCovariance from running sums (oracle::RunningMoments states the recurrence; the device kernels
+    // follow it operation for operation): plain sum in the order of the reference's mean loop, Welford mean, centred
+    // second moment (entries j <= i)
+    std::vector<double> sum, wmean, m2;
+    void push_moments(const double* x, int P) {
+        const double n = static_cast<double>(history_len);  // the state just appended is the n-th
+        const double rn = 1.0 / n, w = (n - 1.0) / n;
+        std::vector<double> d(static_cast<size_t>(P));
+        for (int i = 0; i < P; ++i) d[static_cast<size_t>(i)] = x[i] - wmean[static_cast<size_t>(i)];
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j <= i; ++j)
+                m2[static_cast<size_t>(i) * P + j] += w * (d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)]);
+        for (int i = 0; i < P; ++i) wmean[static_cast<size_t>(i)] += d[static_cast<size_t>(i)] * rn;
+        for (int i = 0; i < P; ++i) sum[static_cast<size_t>(i)] += x[i];
+    }
 };
 
 namespace {
@@ -173,6 +188,10 @@ void MultiChainMetropolisHastings::configure(const std::map<std::string, double>
     target_acceptance_rate_ = get("target_acceptance_rate", 0.234);
     adapt_scale_ = get("adapt_scale", 1.0) != 0.0;
     store_samples_ = get("store_samples", 1.0) != 0.0;
+    // build-side keys (not in the reference's mcmc_settings.txt): the literal two-pass covariance refresh over the whole
+    // history instead of running co-moments, and the ring of newest states the device keeps (default: the period, >= 128)
+    two_pass_covariance_ = get("two_pass_covariance", two_pass_covariance_ ? 1.0 : 0.0) != 0.0;
+    adaptation_window_ = static_cast<int>(get("adaptation_window", static_cast<double>(adaptation_window_)));
 }
 
 OptimizationResult MultiChainMetropolisHastings::optimize(const Eigen::VectorXd& x0, IObjectiveFunction& objective,
@@ -236,7 +255,12 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
             for (int i = 0; i < P; ++i) ch.chol[static_cast<size_t>(i) * P + i] = 0.1;
         }
         ch.mean = ch.x;
-        ch.history.reserve(static_cast<size_t>(iterations_) * P);
+        if (two_pass_covariance_) ch.history.reserve(static_cast<size_t>(iterations_) * P);
+        else {
+            ch.sum.assign(static_cast<size_t>(P), 0.0);
+            ch.wmean.assign(static_cast<size_t>(P), 0.0);
+            ch.m2.assign(PP, 0.0);
+        }
         std::copy(ch.x.begin(), ch.x.end(), batch.begin() + static_cast<size_t>(c) * P);
     }
     eval(batch.data(), C, values.data());  // initial state :257
@@ -253,6 +277,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         ch.lp = values[static_cast<size_t>(c)];
         ch.history.insert(ch.history.end(), ch.x.begin(), ch.x.end());
         ch.history_len = 1;
+        if (!two_pass_covariance_) ch.push_moments(ch.x.data(), P);
         OptimizationResult& r = results[static_cast<size_t>(c)];
         if (store_samples_) { r.samples.push_back(to_eigen(ch.x)); r.sampleObjectiveValues.push_back(ch.lp); }
         r.bestParameters = to_eigen(ch.x);
@@ -267,7 +292,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
             Chain& ch = chains[static_cast<size_t>(c)];
             if (t > burn_in_) {
                 {   // updateCovarianceRank1 :154-166, gamma = 10/(t+100)
-                    const double* ns = &ch.history[(ch.history_len - 1) * static_cast<size_t>(P)];
+                    const double* ns = &ch.history[ch.history.size() - static_cast<size_t>(P)];  // chain_history_.back()
                     const double gamma = 10.0 / (t + 100.0);
                     std::vector<double> diff(static_cast<size_t>(P));
                     for (int i = 0; i < P; ++i) diff[static_cast<size_t>(i)] = ns[i] - ch.mean[static_cast<size_t>(i)];
@@ -279,7 +304,16 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
                                 gamma * (diff[static_cast<size_t>(i)] * diff[static_cast<size_t>(j)]);
                 }
                 if (t % adaptation_period_ == 0) {
-                    if (ch.history_len >= static_cast<size_t>(P) + 10) {  // recomputeFullCovariance :168-199
+                    if (ch.history_len >= static_cast<size_t>(P) + 10 && !two_pass_covariance_) {  // recomputeFullCovariance :168-199
+                        const double len = static_cast<double>(ch.history_len), denom = static_cast<double>(ch.history_len - 1);
+                        for (int i = 0; i < P; ++i) ch.mean[static_cast<size_t>(i)] = ch.sum[static_cast<size_t>(i)] / len;
+                        for (int i = 0; i < P; ++i)
+                            for (int j = 0; j < P; ++j) {
+                                const double m = i >= j ? ch.m2[static_cast<size_t>(i) * P + j] : ch.m2[static_cast<size_t>(j) * P + i];
+                                ch.cov[static_cast<size_t>(i) * P + j] = scaling_factor * (m / denom) + (i == j ? regularization_epsilon_ : 0.0);
+                            }
+                        cholesky(ch.cov, P, ch.chol);  // kept only on success
+                    } else if (ch.history_len >= static_cast<size_t>(P) + 10) {
                         std::vector<double> mean(static_cast<size_t>(P), 0.0), acc(PP, 0.0);
                         for (size_t s = 0; s < ch.history_len; ++s)
                             for (int i = 0; i < P; ++i) mean[static_cast<size_t>(i)] += ch.history[s * P + i];
@@ -369,8 +403,10 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
                 ch.log_scale = std::max(std::min(ch.log_scale, 2.3), -6.9);
                 ch.scale = std::exp(ch.log_scale);
             }
-            ch.history.insert(ch.history.end(), ch.x.begin(), ch.x.end());
+            if (two_pass_covariance_) ch.history.insert(ch.history.end(), ch.x.begin(), ch.x.end());
+            else std::copy(ch.x.begin(), ch.x.end(), ch.history.begin());  // the newest state is all the rank-one update reads
             ch.history_len++;
+            if (!two_pass_covariance_) ch.push_moments(ch.x.data(), P);
             if (store_samples_ && (t % thinning_ == 0)) {
                 r.samples.push_back(to_eigen(ch.x));
                 r.sampleObjectiveValues.push_back(ch.lp);
@@ -420,8 +456,16 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     for (int i = 0; i < P; ++i) cov0[static_cast<size_t>(i) * P + i] += regularization_epsilon_;
 
     sepaihrd_ctx* ctx = objective.deviceContext();
-    sepaihrd_mh* mh = sepaihrd_mh_create(ctx, C, std::max(iterations_, 1), initial.data(), cov0.data(), regularization_epsilon_,
-                                         scaling_factor);
+    sepaihrd_mh_config mcfg{};
+    mcfg.chains = C;
+    mcfg.iterations = std::max(iterations_, 1);
+    mcfg.thinning = store_samples_ ? thinning_ : 0;
+    // every catch-up of the queued updates then falls on a refresh (one launch per adaptation period)
+    mcfg.adaptation_window = adaptation_window_ > 0 ? adaptation_window_ : std::max(adaptation_period_ + 1, 128);
+    mcfg.covariance_mode = two_pass_covariance_ ? SEPAIHRD_MH_COV_TWO_PASS : SEPAIHRD_MH_COV_RUNNING;
+    mcfg.reg_eps = regularization_epsilon_;
+    mcfg.scaling_factor = scaling_factor;
+    sepaihrd_mh* mh = sepaihrd_mh_create(ctx, &mcfg, initial.data(), cov0.data());
     if (!mh) throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_mh_create: ") + sepaihrd_last_error(ctx));
     struct Guard { sepaihrd_mh* p; ~Guard() { sepaihrd_mh_destroy(p); } } guard{mh};
     auto check = [&](int rc, const char* what) {
@@ -458,8 +502,6 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     check(sepaihrd_mh_evaluate_current(mh, values.data(), status.data()), "mh_evaluate_current");  // :257
     sanitize_all();
     traces_.assign(static_cast<size_t>(C), {});
-    std::vector<int32_t> sample_rows;
-    if (store_samples_) sample_rows.push_back(0);
     // generateProposal :91-102 over the chain's queue from element `from` on; returns the elements used
     auto draw_normals = [P](CanonicalQueue& q, size_t from, double* dst) { return standard_normals_from_queue(q, from, dst, P); };
     // adaptGlobalScale (:104-152) as a function of the accept flag: the new log-scale, without touching the chain.
@@ -597,7 +639,6 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         const auto p2 = now();
         // test t -> commit -> adapt -> proposal t + 1 -> evaluation t + 1: queued behind evaluation t
         check(sepaihrd_mh_step_tested(mh, 10.0 / ((t + 1) + 100.0), adapt_mode(t + 1), more ? 0 : 1), "mh_step_tested");
-        if (store_samples_ && (t % thinning_ == 0)) sample_rows.push_back(t);
         const auto p3 = now();
         t_prepare += secs(p1, p2); t_launch += secs(p2, p3);
     }
@@ -617,10 +658,10 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                      1e3 * t_wait / iterations_, 1e3 * t_book / iterations_, 1e3 * t_prepare / iterations_, 1e3 * t_launch / iterations_);
 
     std::vector<double> rows, covs(static_cast<size_t>(C) * PP);
-    const int ns = static_cast<int>(sample_rows.size());
+    const int ns = store_samples_ ? sepaihrd_mh_sample_count(mh) : 0;  // state 0 and every thinning-th one (:266-268,357-360)
     if (ns > 0) {
         rows.resize(static_cast<size_t>(C) * ns * P);
-        check(sepaihrd_mh_read_history(mh, sample_rows.data(), ns, rows.data()), "mh_read_history");
+        check(sepaihrd_mh_read_samples(mh, 0, ns, rows.data()), "mh_read_samples");
     }
     check(sepaihrd_mh_read_covariance(mh, covs.data()), "mh_read_covariance");
     std::vector<OptimizationResult> results(static_cast<size_t>(C));

@@ -238,7 +238,8 @@ int host_current_parameters(void* hv, double* out) {
 int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int iterations, int burn_in,
                 int adaptation_period, int thinning, double reg_eps, double target_acc, int adapt_scale,
                 int use_scalar_interface, int32_t* accepted, double* best_value, double* best, double* final_scale,
-                unsigned char* accept_trace, int32_t* n_samples, double* samples, double* sample_values) {
+                unsigned char* accept_trace, int32_t* n_samples, double* samples, double* sample_values,
+                int two_pass_covariance, double* final_cov, int adaptation_window) {
     auto* h = static_cast<HostHandle*>(hv);
     try {
         const int P = static_cast<int>(h->pm->getParameterCount());
@@ -246,7 +247,8 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
         mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                       {"regularization_epsilon", reg_eps}, {"target_acceptance_rate", target_acc},
-                      {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0}});
+                      {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0},
+                      {"two_pass_covariance", double(two_pass_covariance)}, {"adaptation_window", double(adaptation_window)}});
         mh.setSeed(seed);
         std::vector<OptimizationResult> res;
         if (use_scalar_interface == 1) {
@@ -281,6 +283,9 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                         samples[(static_cast<size_t>(c) * ns + s) * P + i] = r.samples[static_cast<size_t>(s)][i];
             if (sample_values)
                 for (int s = 0; s < ns; ++s) sample_values[static_cast<size_t>(c) * ns + s] = r.sampleObjectiveValues[static_cast<size_t>(s)];
+            if (final_cov)
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j) final_cov[(static_cast<size_t>(c) * P + i) * P + j] = r.finalCovariance(i, j);
         }
         return 0;
     } catch (const std::exception& e) {

@@ -43,7 +43,7 @@ def load_library() -> C.CDLL:
     lib.host_apply_constraints.argtypes = [vp, C.c_int, vp, vp]
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+                                C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]
     lib.host_mh_run_groups.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.host_gradient.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_double, vp, vp]
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -260,32 +260,35 @@ class HostObjective:
 
     def metropolis_hastings(self, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
                             thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
-                            adapt_scale: bool = True, scalar_interface: bool = False, device_state: bool = False) -> dict:
+                            adapt_scale: bool = True, scalar_interface: bool = False, device_state: bool = False,
+                            two_pass_covariance: bool = False, want_trace: bool = True, adaptation_window: int = 0) -> dict:
+        """MultiChainMetropolisHastings (MetropolisHastingsSampler.cpp:201-412 for C lock-step chains): host-state loop,
+        scalar interface, or (device_state) adaptation state resident in HBM.  two_pass_covariance: the reference's
+        literal covariance refresh over the whole history instead of running co-moments."""
         x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
         Cn, P = x0.shape
-        cap = iterations // max(1, thinning) + 2
         accepted = np.zeros(Cn, dtype=np.int32)
         best_value, final_scale = np.zeros(Cn), np.zeros(Cn)
         best = np.zeros((Cn, P))
-        trace = np.zeros((Cn, max(iterations - 1, 1)), dtype=np.uint8)
+        trace = np.zeros((Cn, max(iterations - 1, 1)), dtype=np.uint8) if want_trace else None
         ns = C.c_int32()
-        samples = np.zeros((Cn, cap, P))
-        values = np.zeros((Cn, cap))
-        # first pass to learn n_samples layout is unnecessary: the C side packs with its own n_samples,
-        # so give it exact-size buffers after computing the count here (t = 0 plus every thinning-th t)
-        n_s = 1 + len([t for t in range(1, iterations) if t % max(1, thinning) == 0])
+        # the C side packs with its own n_samples: t = 0 plus every thinning-th t
+        n_s = 1 + (max(iterations, 1) - 1) // max(1, thinning)
         samples = np.zeros((Cn, n_s, P))
         values = np.zeros((Cn, n_s))
+        cov = np.zeros((Cn, P, P))
         rc = self.lib.host_mh_run(self.h, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning,
                                   reg_eps, target_acc, int(adapt_scale), 2 if device_state else int(scalar_interface),
                                   accepted.ctypes.data,
                                   best_value.ctypes.data, best.ctypes.data, final_scale.ctypes.data,
-                                  trace.ctypes.data, C.byref(ns), samples.ctypes.data, values.ctypes.data)
+                                  trace.ctypes.data if want_trace else None, C.byref(ns), samples.ctypes.data,
+                                  values.ctypes.data, int(two_pass_covariance), cov.ctypes.data, int(adaptation_window))
         if rc:
             raise RuntimeError(self.lib.host_last_error().decode())
         assert ns.value == n_s
         return {"accepted": accepted, "best_value": best_value, "best": best, "final_scale": final_scale,
-                "accept_trace": trace[:, :iterations - 1], "samples": samples, "sample_values": values,
+                "accept_trace": trace[:, :iterations - 1] if want_trace else None, "samples": samples,
+                "sample_values": values, "final_cov": cov,
                 "loop_seconds": float(self.lib.host_last_mh_loop_seconds())}
 
 

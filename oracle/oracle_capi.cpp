@@ -183,7 +183,7 @@ int oracle_mh(void* hv, int iterations, int burn_in, int adaptation_period, int 
               double reg_eps, double target_acc, int adapt_scale, const double* x0, uint32_t seed,
               double* best, double* best_value, int32_t* accepted, double* final_scale,
               unsigned char* accept_trace, double* samples, double* sample_values,
-              int32_t* n_samples, double* final_cov) {
+              int32_t* n_samples, double* final_cov, int two_pass_covariance) {
     const Handle* h = static_cast<Handle*>(hv);
     oracle::Problem pb = h->pb;  // private copy: the sampler flips the constraint mode
     const int P = (int)pb.pm.names.size();
@@ -191,6 +191,7 @@ int oracle_mh(void* hv, int iterations, int burn_in, int adaptation_period, int 
     cfg.iterations = iterations; cfg.burn_in = burn_in; cfg.adaptation_period = adaptation_period;
     cfg.thinning = std::max(1, thinning); cfg.regularization_epsilon = reg_eps;
     cfg.target_acceptance_rate = target_acc; cfg.adapt_scale = adapt_scale != 0;
+    cfg.two_pass_covariance = two_pass_covariance != 0;
     oracle::Objective f = [&pb](const std::vector<double>& th) {
         oracle::EvalInfo info;
         double v = oracle::objective(pb, th, &info, nullptr);

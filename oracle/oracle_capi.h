@@ -44,12 +44,14 @@ int oracle_jitter_draws(void *h, int mode, const double *base, uint32_t seed0, i
 uint64_t oracle_cache_hash(const double *p, int size);
 /* n standard normals from mt19937(seed) with ONE persistent std::normal_distribution */
 void oracle_std_normals(uint32_t seed, int count, double *out);
-/* Adaptive Metropolis, one chain. samples: (iterations/thinning + 1) x P capacity given by caller. */
+/* Adaptive Metropolis, one chain. samples: (iterations/thinning + 1) x P capacity given by caller.
+ * two_pass_covariance: 0 = covariance refresh from running co-moments (oracle::RunningMoments), 1 = the literal two
+ * passes over the whole chain history of recomputeFullCovariance (MetropolisHastingsSampler.cpp:168-199). */
 int oracle_mh(void *h, int iterations, int burn_in, int adaptation_period, int thinning,
               double reg_eps, double target_acc, int adapt_scale, const double *x0, uint32_t seed,
               double *best, double *best_value, int32_t *accepted, double *final_scale,
               unsigned char *accept_trace, double *samples, double *sample_values,
-              int32_t *n_samples, double *final_cov);
+              int32_t *n_samples, double *final_cov, int two_pass_covariance);
 /* Posterior ensemble summaries from a FIXED initial state (SimulationRunner::runSimulation):
  * ppc [6][n_probs][Tp][n], sero [n_probs][T], status [S]; returns Tp, n_valid via pointers. */
 int oracle_ensemble(void *h, const double *theta, int S, const double *probs, int n_probs, double *ppc,

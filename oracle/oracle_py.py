@@ -67,7 +67,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.oracle_cache_hash.argtypes = [vp, C.c_int]
     lib.oracle_std_normals.argtypes = [C.c_uint32, C.c_int, vp]
     lib.oracle_mh.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
-                              C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                              C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_hc.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     lib.oracle_pso.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
@@ -339,7 +339,7 @@ class Oracle:
 
     def metropolis_hastings(self, x0, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
                             thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
-                            adapt_scale: bool = True) -> dict:
+                            adapt_scale: bool = True, two_pass_covariance: bool = False) -> dict:
         P = self.P
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         cap = iterations // max(1, thinning) + 2
@@ -353,7 +353,7 @@ class Oracle:
         self.lib.oracle_mh(self.h, iterations, burn_in, adaptation_period, thinning, reg_eps, target_acc,
                            int(adapt_scale), x0.ctypes.data, seed, best.ctypes.data, C.byref(best_value),
                            C.byref(accepted), C.byref(final_scale), trace.ctypes.data, samples.ctypes.data,
-                           values.ctypes.data, C.byref(n_samples), cov.ctypes.data)
+                           values.ctypes.data, C.byref(n_samples), cov.ctypes.data, int(two_pass_covariance))
         ns = n_samples.value
         return {"best": best, "best_value": best_value.value, "accepted": accepted.value,
                 "final_scale": final_scale.value, "accept_trace": trace[:iterations - 1],

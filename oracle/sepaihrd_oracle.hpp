@@ -1005,6 +1005,51 @@ struct MHSettings {
     double regularization_epsilon = 1e-6, target_acceptance_rate = 0.234;
     bool adapt_scale = true;
     std::vector<double> initial_cov;  // setInitialCovariance (:52-63): P x P row-major, empty = none
+    // recomputeFullCovariance (:168-199): false = running co-moments (RunningMoments below, O(P^2) per iteration whatever t),
+    // true = the literal two passes over the whole history (O(t P^2) per refresh, every state kept)
+    bool two_pass_covariance = false;
+};
+
+// -----------------------------------------------------------------------------
+// The sample covariance of recomputeFullCovariance (:168-199) carried as running sums, so that a refresh costs
+// O(P^2) instead of a walk over the whole chain history and no history has to be kept.
+//   sum    plain running sum of the states, added in the order the reference's own loop adds them
+//          (`for vec in chain_history_: mean += vec`, :171-174): sum / len IS the reference's mean, bit for bit;
+//   mean,  Welford's recurrence for the centred second moment, n = number of states so far, d = x - mean (old):
+//   m2        m2_ij += ((n - 1) / n) * (d_i * d_j);   mean_i += d_i * (1 / n)
+//          (the symmetric form: the bits of m2_ij and m2_ji are the same, only j <= i is stored).
+// At a refresh  cov_ij = scaling * (m2_ij / (len - 1)) + eps [i == j].  The reference forms the same matrix as
+// `centered.adjoint() * centered` through Eigen's blocked GEMM (:184), whose summation order nothing in the
+// reference tree pins; this recurrence is the order the build chose, stated once here and followed by the host
+// library and the device kernels operation for operation (no contraction), so that all three give the same bits.
+// Agreement with the two-pass form: ~1e-13 relative (tests/test_oracle_golden.py).
+// -----------------------------------------------------------------------------
+struct RunningMoments {
+    int P = 0;
+    long n = 0;
+    std::vector<double> sum, mean, m2;  // m2: P x P row-major, entries j <= i
+    explicit RunningMoments(int P_ = 0) : P(P_), sum(P_, 0.0), mean(P_, 0.0), m2(static_cast<size_t>(P_) * P_, 0.0) {}
+    void push(const double* x) {
+        n += 1;
+        const double rn = 1.0 / static_cast<double>(n);
+        const double w = static_cast<double>(n - 1) / static_cast<double>(n);
+        std::vector<double> d(P);
+        for (int i = 0; i < P; ++i) d[i] = x[i] - mean[i];
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j <= i; ++j) m2[static_cast<size_t>(i) * P + j] += w * (d[i] * d[j]);
+        for (int i = 0; i < P; ++i) mean[i] += d[i] * rn;
+        for (int i = 0; i < P; ++i) sum[i] += x[i];
+    }
+    // running_mean_ = mean (:175-176) and current_covariance_ (:184-190) of a history of n states
+    void covariance(double scaling, double eps, std::vector<double>& running_mean, std::vector<double>& cov) const {
+        const double len = static_cast<double>(n), denom = static_cast<double>(n - 1);
+        for (int i = 0; i < P; ++i) running_mean[i] = sum[i] / len;
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j) {
+                const double m = i >= j ? m2[static_cast<size_t>(i) * P + j] : m2[static_cast<size_t>(j) * P + i];
+                cov[static_cast<size_t>(i) * P + j] = scaling * (m / denom) + (i == j ? eps : 0.0);
+            }
+    }
 };
 
 struct MHResult {
@@ -1072,9 +1117,14 @@ inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<dou
     std::vector<double> running_mean = x0;
     double log_scale = 0.0, global_scale = 1.0;
     double cur_lp = safe_eval(cur);
+    // chain_history_ (:262-264): kept whole only for the literal two-pass refresh; otherwise its running sums
+    // and the newest state, which is all updateCovarianceRank1 reads (:157)
     std::vector<std::vector<double>> history;
-    history.reserve(cfg.iterations);
+    RunningMoments moments(P);
+    size_t history_len = 1;
+    if (cfg.two_pass_covariance) history.reserve(cfg.iterations);
     history.push_back(cur);
+    moments.push(cur.data());
     r.samples.push_back(cur);
     r.sample_values.push_back(cur_lp);
     r.best = cur;
@@ -1098,7 +1148,11 @@ inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<dou
             }
             if (t % cfg.adaptation_period == 0) {
                 // recomputeFullCovariance :168-199
-                if (history.size() >= static_cast<size_t>(P) + 10) {
+                if (history_len >= static_cast<size_t>(P) + 10 && !cfg.two_pass_covariance) {
+                    moments.covariance(scaling_factor, cfg.regularization_epsilon, running_mean, cov);
+                    std::vector<double> Ltry;
+                    if (cholesky_lower(cov, P, Ltry)) L = Ltry;
+                } else if (history_len >= static_cast<size_t>(P) + 10) {
                     std::vector<double> mean(P, 0.0);
                     for (const auto& v : history)
                         for (int i = 0; i < P; ++i) mean[i] += v[i];
@@ -1175,7 +1229,10 @@ inline MHResult metropolis_hastings(const MHSettings& cfg, const std::vector<dou
             log_scale = std::max(std::min(log_scale, 2.3), -6.9);
             global_scale = std::exp(log_scale);
         }
-        history.push_back(cur);
+        if (cfg.two_pass_covariance) history.push_back(cur);
+        else history.back() = cur;
+        history_len++;
+        moments.push(cur.data());
         if (t % cfg.thinning == 0) {
             r.samples.push_back(cur);
             r.sample_values.push_back(cur_lp);

@@ -85,17 +85,24 @@ int main(void) {
         memcpy(start, theta, sizeof start);
         start[6] = 0.5;  /* inside the bounds, so that z = 0 proposes the state itself */
         memset(z, 0, sizeof z);
-        sepaihrd_mh* mh = sepaihrd_mh_create(ctx, 3, 8, start, cov0, 1e-6, 2.38 * 2.38 / P);
+        double kept[3 * 2 * P];
+        sepaihrd_mh_config cfg;
+        sepaihrd_mh* mh;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.chains = 3; cfg.iterations = 8; cfg.thinning = 1; cfg.adaptation_window = 4;
+        cfg.covariance_mode = SEPAIHRD_MH_COV_RUNNING; cfg.reg_eps = 1e-6; cfg.scaling_factor = 2.38 * 2.38 / P;
+        mh = sepaihrd_mh_create(ctx, &cfg, start, cov0);
         if (!mh) { fprintf(stderr, "mh_create: %s\n", sepaihrd_last_error(ctx)); return 7; }
         if (sepaihrd_mh_evaluate_current(mh, cur, NULL) != SEPAIHRD_OK || sepaihrd_mh_propose(mh, z, scale, prop, NULL) != SEPAIHRD_OK ||
             sepaihrd_mh_commit(mh, accept) != SEPAIHRD_OK || sepaihrd_mh_adapt(mh, 0.1, 1, 0) != SEPAIHRD_OK ||
-            sepaihrd_mh_read_history(mh, rows, 2, hist) != SEPAIHRD_OK) {
+            sepaihrd_mh_read_history(mh, rows, 2, hist) != SEPAIHRD_OK || sepaihrd_mh_read_samples(mh, 0, 2, kept) != SEPAIHRD_OK) {
             fprintf(stderr, "sampler entry point failed: %s\n", sepaihrd_last_error(ctx));
             return 8;
         }
         for (i = 0; i < 3; ++i)
             if (cur[i] != prop[i]) { fprintf(stderr, "z = 0 must propose the current state\n"); return 9; }
-        if (sepaihrd_mh_history_length(mh) != 2 || hist[0] != start[0] || hist[P] != start[0]) { fprintf(stderr, "history mismatch\n"); return 10; }
+        if (sepaihrd_mh_history_length(mh) != 2 || sepaihrd_mh_sample_count(mh) != 2 || hist[0] != start[0] || hist[P] != start[0] ||
+            memcmp(hist, kept, sizeof hist) != 0) { fprintf(stderr, "history mismatch\n"); return 10; }
         sepaihrd_mh_destroy(mh);
     }
     sepaihrd_destroy(ctx);

@@ -2,6 +2,8 @@
 HipSEPAIHRDObjectiveFunction, SimulationCache semantics, and the multi-chain Adaptive-Metropolis
 driver against the oracle's restatement of MetropolisHastingsSampler (bit-exact accept/reject
 sequences for a fixed seed)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -351,6 +353,179 @@ def test_device_sampler_accept_traces_in_production_arithmetic(mm, oracle_py, sy
         np.testing.assert_allclose(dev["final_scale"][c], ref["final_scale"], rtol=1e-14)
 
 
+def test_covariance_refresh_from_running_moments_against_the_two_pass_form(mm, oracle_py, shipped):
+    """recomputeFullCovariance (MetropolisHastingsSampler.cpp:168-199) from running co-moments (the default: O(P^2) per
+    refresh, no history) against the reference's two literal passes over the whole history, both on the device and both
+    bit-identical to the host loop and to the oracle in the same mode; between the modes the final covariances agree to
+    1e-11 of their largest entry, the refreshed running mean is the same sum in the same order (the samples -- proposals
+    formed from the factor -- differ by rounding only) and the accept traces are equal."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    C, iters, burn, ap = 5, 330, 80, 50
+    x0 = oracle_py.Oracle(pb).jitter_draws(pb.base_theta, 3, C, mode=1)
+    kw = dict(seed=43, iterations=iters, burn_in=burn, adaptation_period=ap, thinning=7)
+    out = {}
+    for two_pass in (False, True):
+        host = mm.HostObjective(pb).metropolis_hastings(x0, two_pass_covariance=two_pass, **kw)
+        dev = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, two_pass_covariance=two_pass, **kw)
+        for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+            assert np.array_equal(dev[k], host[k]), (two_pass, k)
+        ref = oracle_py.Oracle(pb).metropolis_hastings(x0[1], 43 + 1, iters, burn, adaptation_period=ap, thinning=7,
+                                                       two_pass_covariance=two_pass)
+        assert np.array_equal(dev["accept_trace"][1], ref["accept_trace"])
+        assert np.array_equal(dev["final_cov"][1], ref["final_cov"])
+        assert np.array_equal(dev["samples"][1], ref["samples"])
+        out[two_pass] = dev
+    a, b = out[False], out[True]
+    assert np.array_equal(a["accept_trace"], b["accept_trace"])
+    scale = np.abs(b["final_cov"]).max(axis=(1, 2), keepdims=True)
+    # ~1e-13 per refresh; the states themselves then differ by rounding (proposals are formed from the factors)
+    assert (np.abs(a["final_cov"] - b["final_cov"]) / scale).max() < 1e-11
+    np.testing.assert_allclose(a["samples"], b["samples"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("window", [2, 7, 33])
+def test_ring_of_newest_states_smaller_than_the_adaptation_period(mm, shipped, window):
+    """The device keeps the newest `adaptation_window` states only; queued rank-one and co-moment updates are caught up
+    before the ring overwrites a state they read.  Whatever the window -- 2 (every commit forces a catch-up), 7, 33
+    against a period of 40 -- the run is the default one bit for bit, final covariance (rank-one updates after the last
+    refresh) included."""
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 5, 4)
+    kw = dict(seed=29, iterations=215, burn_in=30, adaptation_period=40, thinning=3)
+    want = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)
+    got = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, adaptation_window=window, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_sampler_entry_points_in_any_call_pattern(mm, shipped):
+    """sepaihrd_mh_adapt reads the NEWEST state whatever came before it: commit, commit, adapt, commit, adapt, adapt
+    (updates queued with the state they read, applied when the covariance is read) against a numpy restatement of
+    updateCovarianceRank1 (MetropolisHastingsSampler.cpp:154-166) applied at once; then the running moments, the
+    stored samples, the summary records (means, variances, best value, accepted count) and the bounds of
+    read_history / read_samples."""
+    import ctypes as C
+    from mmid_amd import draws, hipabi
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=mm.CONSTRAINT_REFLECT)
+    Cn, P = 9, pb.n_params
+    lib = hipabi.load_library()
+    rng = np.random.default_rng(5)
+    x0 = draws.jitter_draws(pb, 3, Cn)
+    cov0 = np.diag((0.02 * np.maximum(np.abs(pb.base_theta), 1e-3)) ** 2) + 1e-6 * np.eye(P)
+    hip = mm.HipObjective(pb)
+    mh = hipabi.mh_create(lib, hip.ctx, Cn, 12, x0, cov0, thinning=2, adaptation_window=3)
+    assert mh
+    lp0 = np.empty(Cn)
+    assert lib.sepaihrd_mh_evaluate_current(mh, lp0.ctypes.data, None) == 0
+    states = [x0.copy()]
+    cov = np.repeat(cov0[None], Cn, axis=0)
+    mean = x0.copy()
+    accepted = np.zeros(Cn)
+
+    def step(accept_mask):
+        z = rng.standard_normal((Cn, P))
+        scale = np.full(Cn, 0.4)
+        ll = np.empty(Cn)
+        assert lib.sepaihrd_mh_propose(mh, z.ctypes.data, scale.ctypes.data, ll.ctypes.data, None) == 0
+        prop = np.empty((Cn, P))
+        assert lib.sepaihrd_mh_read_proposal(mh, prop.ctypes.data) == 0
+        acc = np.ascontiguousarray(accept_mask, dtype=np.uint8)
+        assert lib.sepaihrd_mh_commit(mh, acc.ctypes.data) == 0
+        states.append(np.where(acc[:, None] & 1, prop, states[-1]))
+        accepted[:] += acc & 1
+
+    def adapt(gamma):
+        assert lib.sepaihrd_mh_adapt(mh, gamma, 0, 0) == 0
+        d = states[-1] - mean
+        cov[:] = (1.0 - gamma) * cov + gamma * (d[:, :, None] * d[:, None, :])
+        mean[:] += gamma * d
+
+    pattern = np.arange(Cn) % 2
+    step(pattern); step(1 - pattern); adapt(0.3); step(pattern); adapt(0.2); adapt(0.1)
+    step(np.ones(Cn)); step(pattern); step(1 - pattern)   # the ring (3 states) wraps over the states the updates read
+    got = np.empty((Cn, P, P))
+    assert lib.sepaihrd_mh_read_covariance(mh, got.ctypes.data) == 0
+    assert np.array_equal(got, cov)
+    # running moments of all 7 states against numpy (different summation order: agreement, not identity)
+    hist = np.stack(states, axis=1)                      # [C][7][P]
+    wmean, m2 = np.empty((Cn, P)), np.empty((Cn, P, P))
+    assert lib.sepaihrd_mh_read_moments(mh, wmean.ctypes.data, m2.ctypes.data) == 0
+    np.testing.assert_allclose(wmean, hist.mean(axis=1), rtol=1e-13)
+    dev = hist - hist.mean(axis=1, keepdims=True)
+    want_m2 = np.einsum("csi,csj->cij", dev, dev)
+    il = np.tril_indices(P)
+    assert np.abs(m2[:, il[0], il[1]] - want_m2[:, il[0], il[1]]).max() <= 1e-12 * np.abs(want_m2).max()
+    # samples: states 0, 2, 4, 6
+    assert lib.sepaihrd_mh_history_length(mh) == 7 and lib.sepaihrd_mh_sample_count(mh) == 4
+    kept = np.empty((Cn, 4, P))
+    assert lib.sepaihrd_mh_read_samples(mh, 0, 4, kept.ctypes.data) == 0
+    assert np.array_equal(kept, hist[:, ::2])
+    assert lib.sepaihrd_mh_read_samples(mh, 2, 3, kept.ctypes.data) != 0      # beyond what is stored
+    rows = np.array([4, 6], dtype=np.int32)
+    two = np.empty((Cn, 2, P))
+    assert lib.sepaihrd_mh_read_history(mh, rows.ctypes.data, 2, two.ctypes.data) == 0
+    assert np.array_equal(two, hist[:, [4, 6]])
+    rows[0] = 3                                                                # left the ring of 3
+    assert lib.sepaihrd_mh_read_history(mh, rows.ctypes.data, 2, two.ctypes.data) != 0
+    # summary records over samples 1.. (states 2, 4, 6)
+    lib.sepaihrd_mh_set_values.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.sepaihrd_mh_set_values(mh, lp0.ctypes.data) == 0
+    rec = np.empty((Cn, 2 * P + 2))
+    assert lib.sepaihrd_mh_summary_records(mh, 1, rec.ctypes.data, None) == 0
+    np.testing.assert_allclose(rec[:, :P], hist[:, 2::2].mean(axis=1), rtol=1e-14)
+    np.testing.assert_allclose(rec[:, P:2 * P], hist[:, 2::2].var(axis=1, ddof=1), rtol=1e-9, atol=1e-30)
+    assert np.array_equal(rec[:, 2 * P], lp0) and np.array_equal(rec[:, 2 * P + 1], accepted)
+    lib.sepaihrd_mh_destroy(mh)
+
+
+def test_sampler_state_fits_at_the_reference_run_length(mm, shipped):
+    """data/configuration/mcmc_settings.txt: 100 000 iterations, thinning 100.  The sampler state of BASELINE configs[2]'s
+    65 536 chains fits the device (ring + samples + covariance, factor and second moment: ~47 GB) where the whole history
+    (65 536 x 100 000 x 62 doubles = 3.25 TB) could not; the two-pass mode says so instead of failing in an allocation."""
+    from mmid_amd import hipabi
+    pb = shipped.with_(constraint_mode=1)
+    lib = hipabi.load_library()
+    hip = mm.HipObjective(pb)
+    P = pb.n_params
+    x0 = np.repeat(np.asarray(pb.base_theta)[None], 65536, axis=0)
+    cov0 = 1e-4 * np.eye(P)
+    assert not hipabi.mh_create(lib, hip.ctx, 65536, 100000, x0, cov0, thinning=100, covariance_mode=hipabi.MH_COV_TWO_PASS)
+    assert b"GB" in lib.sepaihrd_last_error(hip.ctx)
+    mh = hipabi.mh_create(lib, hip.ctx, 65536, 100000, x0, cov0, thinning=100)
+    assert mh, lib.sepaihrd_last_error(hip.ctx)
+    lib.sepaihrd_mh_destroy(mh)
+
+
+def test_headline_batch_accept_traces_in_production_arithmetic(mm, oracle_py, synth400):
+    """The acceptance contract of the arithmetic `bench.py`'s value is measured in, at the headline batch: the
+    device-resident sampler in fma arithmetic, 4096 chains x 300 iterations with covariance refreshes, against the
+    STRICT oracle's MetropolisHastingsSampler restatement chain by chain (MetropolisHastingsSampler.cpp:318-330).
+    Expected mismatches: 0.  A likelihood that differs in the 9th digit flips an accept test whose uniform falls inside
+    that gap (probability ~1e-9 x |log-likelihood| per test): the assertion allows none, and says how many if any."""
+    from concurrent.futures import ThreadPoolExecutor
+    pb = synth400.with_(arith=mm.ARITH_FMA, constraint_mode=1, solver=0)
+    C, iters, burn, ap = 4096, 300, 100, 50
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 1, C)
+    kw = dict(iterations=iters, burn_in=burn, adaptation_period=ap, thinning=50)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, seed=1000, device_state=True, **kw)
+    orc = oracle_py.Oracle(pb.with_(arith=mm.ARITH_STRICT))
+
+    def one(c):
+        ref = orc.metropolis_hastings(x0[c], 1000 + c, iters, burn, adaptation_period=ap, thinning=50)
+        return ref["accept_trace"], ref["accepted"]
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(one, range(C)))
+    trace = np.stack([r[0] for r in refs])
+    mismatches = int((trace != dev["accept_trace"]).sum())
+    chains_off = int((trace != dev["accept_trace"]).any(axis=1).sum())
+    assert mismatches == 0, f"{mismatches} accept decisions differ in {chains_off} of {C} chains"
+    assert np.array_equal(dev["accepted"], np.array([r[1] for r in refs]))
+    assert 0.02 < dev["accept_trace"].mean() < 0.9
+
+
 def test_reference_constructor_argument_lists(mm, shipped):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,
@@ -407,7 +582,7 @@ def test_device_accept_test_against_the_host_driven_step(mm, shipped):
 
     def sampler():
         hip = mm.HipObjective(pb)
-        mh = lib.sepaihrd_mh_create(hip.ctx, Cn, 8, x0.ctypes.data, cov0.ctypes.data, 1e-6, 2.38 * 2.38 / P)
+        mh = hipabi.mh_create(lib, hip.ctx, Cn, 8, x0, cov0)
         assert mh
         lp0, st0 = np.empty(Cn), np.empty(Cn, dtype=np.int32)
         assert lib.sepaihrd_mh_evaluate_current(mh, lp0.ctypes.data, st0.ctypes.data) == 0

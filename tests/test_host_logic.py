@@ -36,6 +36,16 @@ def test_struct_layout_matches_header_field_order(mm):
     assert names == [f for f, _ in mm.hipabi.sepaihrd_problem._fields_]
 
 
+def test_sampler_config_struct_matches_header(mm):
+    header = open(os.path.join(ROOT, "include", "sepaihrd_hip.h")).read()
+    start = header.index("typedef struct sepaihrd_mh_config {") + len("typedef struct sepaihrd_mh_config {")
+    body = re.sub(r"/\*.*?\*/", "", header[start:header.index("} sepaihrd_mh_config;")], flags=re.S)
+    fields = [(m.group(1), m.group(2)) for m in re.finditer(r"(int32_t|double)\s+([a-z_]+);", body)]
+    ctype = {"int32_t": ctypes.c_int32, "double": ctypes.c_double}
+    assert [(n, ctype[t]) for t, n in fields] == list(mm.hipabi.sepaihrd_mh_config._fields_)
+    assert ctypes.sizeof(mm.hipabi.sepaihrd_mh_config) == 6 * 4 + 2 * 8
+
+
 def test_create_fails_loudly_without_gpu(mm, shipped, have_gpu):
     if have_gpu:
         pytest.skip("GPU present")

@@ -286,3 +286,20 @@ def test_nuts_restatement_properties(mm, oracle_py, ref_fixture):
     assert 10 + 3 <= a["gradient_calls"] <= 10 + 3 * leaves_max + 3 * 6 + 1
     # the stored value is the objective at the stored (constrained) sample
     np.testing.assert_allclose(a["sample_values"][-1], orc.calculate(a["samples"][-1]), rtol=1e-12)
+
+
+def test_running_comoment_covariance_against_the_two_pass_form(mm, oracle_py, shipped):
+    """oracle::RunningMoments (the recurrence host library and device kernels follow) against the literal restatement
+    of recomputeFullCovariance (MetropolisHastingsSampler.cpp:168-199) inside the same sampler: covariances equal to
+    1e-12 of the largest entry after six refreshes, accept traces equal, samples equal to rounding."""
+    pb = shipped.with_(constraint_mode=1)
+    orc = oracle_py.Oracle(pb)
+    x0 = orc.jitter_draws(pb.base_theta, 3, 1, mode=1)[0]
+    kw = dict(adaptation_period=50, thinning=5)
+    a = orc.metropolis_hastings(x0, 17, 420, 100, **kw)
+    b = orc.metropolis_hastings(x0, 17, 420, 100, two_pass_covariance=True, **kw)
+    assert 0 < a["accepted"] < 419
+    assert np.array_equal(a["accept_trace"], b["accept_trace"])
+    assert np.abs(a["final_cov"] - b["final_cov"]).max() <= 1e-12 * np.abs(b["final_cov"]).max()
+    np.testing.assert_allclose(a["samples"], b["samples"], rtol=1e-10, atol=1e-13)
+    assert np.array_equal(a["final_cov"], a["final_cov"].T)
