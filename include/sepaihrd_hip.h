@@ -183,6 +183,15 @@ int sepaihrd_abi_version(void);
 int sepaihrd_set_constraint_mode(sepaihrd_ctx *ctx, int mode);
 int sepaihrd_set_arith(sepaihrd_ctx *ctx, int arith);
 int sepaihrd_set_precision(sepaihrd_ctx *ctx, int precision);
+/* Which form of the fp64 integrator a launch uses.  AUTO (default): by batch size -- up to 4096 chains of a problem with
+ * 3 or 4 age classes sixteen lanes integrate a chain (a quad of lanes per age class, so that a batch too small to fill
+ * the chip spreads over four times as many SIMDs), beyond that one lane per (chain, age class).  Both forms round every
+ * operation alike: log-likelihood, status, step counts and trajectories are the same bits, and the parity suite proves it
+ * by forcing each form on the same chains.  QUAD on other age counts: SEPAIHRD_E_UNSUPPORTED. */
+#define SEPAIHRD_FORM_AUTO 0
+#define SEPAIHRD_FORM_LANE_PER_AGE 1
+#define SEPAIHRD_FORM_QUAD 2
+int sepaihrd_set_integrator_form(sepaihrd_ctx *ctx, int form);
 
 /* Host-pointer form.  theta: B x P, chain-major (one Eigen::VectorXd after another).
  * Outputs (any may be NULL except loglik): loglik[B]; status[B]; n_accept[B]/n_reject[B] =

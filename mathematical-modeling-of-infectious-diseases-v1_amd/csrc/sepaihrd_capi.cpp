@@ -689,6 +689,16 @@ int sepaihrd_set_initial_state_mode(sepaihrd_ctx* ctx, int mode) {
     return SEPAIHRD_OK;
 }
 
+int sepaihrd_set_integrator_form(sepaihrd_ctx* ctx, int form) {
+    if (!ctx || form < SEPAIHRD_FORM_AUTO || form > SEPAIHRD_FORM_QUAD) return SEPAIHRD_E_INVALID_ARG;
+    if (form == SEPAIHRD_FORM_QUAD && ctx->dp.lpc != 4) {
+        ctx->last_error = "set_integrator_form: the sixteen-lanes-per-chain form exists for problems of 3 or 4 age classes";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
+    ctx->dp.form = form;
+    return SEPAIHRD_OK;
+}
+
 int sepaihrd_ensemble_quantiles(sepaihrd_ctx* ctx, const double* theta, int S, const double* probs, int n_probs,
                                 double* ppc_quantiles, double* sero_quantiles, double* rt_quantiles, double* metrics,
                                 int32_t* status, int32_t* n_valid) {

@@ -26,6 +26,7 @@ struct DevProblem {
     int32_t n, lpc, T, n_obs, runup_offset, nb, nk, P, ns;
     int32_t constraint_mode, kappa_calibrated, max_attempts, obs_rows_match;
     int32_t init_mode;  // 0: from theta (objective), 1: problem.initial_state as given (ensemble), 2: multipliers always (FD gradient)
+    int32_t form;       // SEPAIHRD_FORM_*: which form of the integrator a launch uses (0 = by batch size); same bits either way
     double abs_tol, rel_tol, dt_hint, max_gap;
     const double* times;         // [T]
     // per output point k and lane (age): {obs_H, obs_ICU, obs_D, times[k+1]} -- 32 bytes, fetched by

@@ -1022,27 +1022,38 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_reduce_kernel(const DevProbl
 #endif
 #include "sepaihrd_lane_split.inc"  // 16-lanes-per-chain form for small batches of the 4-age model
 
-// SEPAIHRD_LANE_SPLIT=0 keeps every launch on the 4-lane kernel, =1 uses the 16-lane form at any batch size
-// (measurement switches); unset: up to QUAD_MAX_CHAINS chains.
-inline bool lane_split_wanted(int B) {
+// Which form integrates a batch of B chains of a 4-age problem: the 16-lane form up to QUAD_MAX_CHAINS chains, unless
+// the context asks for one form (sepaihrd_set_integrator_form: the parity tests run the same chains through both).
+// Experiment builds (-DSEPAIHRD_EXPERIMENTS, tools/ only): SEPAIHRD_LANE_SPLIT=0|1 overrides from the environment.
+inline bool lane_split_wanted(const DevProblem& pb, int B) {
+#ifdef SEPAIHRD_EXPERIMENTS
     static const int mode = [] {
         const char* e = getenv("SEPAIHRD_LANE_SPLIT");
         return e == nullptr ? -1 : atoi(e);
     }();
-    return mode < 0 ? B <= QUAD_MAX_CHAINS : mode != 0;
+    if (mode >= 0) return mode != 0;
+#endif
+    return pb.form == 0 ? B <= QUAD_MAX_CHAINS : pb.form == 2;
 }
-#if SEPAIHRD_ARITH_FMA
-#include "sepaihrd_wave_chain.inc"  // one wavefront per chain: the latency form for batches of up to WAVE_CHAIN_MAX chains
+#if SEPAIHRD_ARITH_FMA && defined(SEPAIHRD_EXPERIMENTS)
+#include "sepaihrd_wave_chain.inc"  // one wavefront per chain (measured, loses everywhere; not in the shipped library)
+#define SEPAIHRD_HAVE_WAVE_CHAIN 1
+#else
+#define SEPAIHRD_HAVE_WAVE_CHAIN 0
 #endif
 
-// SEPAIHRD_LL_SERIAL_MIN_WAVES=n overrides the batch size from which the separate likelihood pass walks the days in one
-// lane per (chain, stream) (measurement switch; both forms give the same bits)
+// (chain, stream) waves from which the separate likelihood pass walks the days in one lane per (chain, stream); both
+// forms give the same bits.  Experiment builds: SEPAIHRD_LL_SERIAL_MIN_WAVES=n overrides.
+template <int LPC>
 inline int ll_serial_min_waves() {
+#ifdef SEPAIHRD_EXPERIMENTS
     static const int v = [] {
         const char* e = getenv("SEPAIHRD_LL_SERIAL_MIN_WAVES");
-        return e == nullptr ? LL_SERIAL_MIN_WAVES : atoi(e);
+        return e == nullptr ? -1 : atoi(e);
     }();
-    return v;
+    if (v >= 0) return v;
+#endif
+    return LL_SERIAL_MIN_WAVES;
 }
 
 // ----------------------------------------------------------------------------------
@@ -1060,7 +1071,7 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
                        st, pb, d_theta, B, out, cum_chains);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
-        if ((B + WAVE - 1) / WAVE >= ll_serial_min_waves() / 3) {
+        if ((B + WAVE - 1) / WAVE >= ll_serial_min_waves<LPC>() / 3) {
             hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC>), dim3((B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out,
                                cum_chains);
             hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains, 1);
@@ -1080,14 +1091,14 @@ int needs_workspace_one(const DevProblem& pb, int B, int force_split) {
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
-#if SEPAIHRD_ARITH_FMA
+#if SEPAIHRD_HAVE_WAVE_CHAIN
     if constexpr (LPC == 4) {
         if (wave_chain_wanted(B)) return 1;  // the one-wave-per-chain form parks its increments
     }
 #endif
     if constexpr (LPC == 4) {
         // the 16-lane form evaluates the likelihood on consumer waves of the same workgroup: no workspace
-        if (lane_split_wanted(B)) return (quad_fused_wanted() && !force_split && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS) ? 0 : 1;
+        if (lane_split_wanted(pb, B)) return (quad_fused_wanted() && !force_split && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS) ? 0 : 1;
     }
     return (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || force_split) ? 1 : 0;
 }
@@ -1097,13 +1108,13 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
-#if SEPAIHRD_ARITH_FMA
+#if SEPAIHRD_HAVE_WAVE_CHAIN
     if constexpr (LPC == 4) {
         if (wave_chain_wanted(B)) return launch_wave_chain<SOLVER>(pb, d_theta, B, out, stream);
     }
 #endif
     if constexpr (LPC == 4) {
-        if (lane_split_wanted(B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
+        if (lane_split_wanted(pb, B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
     if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
@@ -1134,14 +1145,14 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
 
 template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
-#if SEPAIHRD_ARITH_FMA
+#if SEPAIHRD_HAVE_WAVE_CHAIN
     if constexpr (LPC == 4) {
         if (batch > 0 && wave_chain_wanted(batch))
             return info_of(&sepaihrd_eval_wave_kernel<SOLVER>, pb, WAVE, info, "sepaihrd_eval_wave_kernel[fma]", WAVE, wave_chain_lds_bytes(pb));
     }
 #endif
     if constexpr (LPC == 4) {
-        if (batch > 0 && lane_split_wanted(batch))
+        if (batch > 0 && lane_split_wanted(pb, batch))
             return quad_fused_wanted() ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", 8 * WAVE, quad_fused_lds_bytes(pb))
                                        : info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
     }

@@ -62,6 +62,7 @@ class sepaihrd_mh_config(C.Structure):
 
 
 MH_COV_RUNNING, MH_COV_TWO_PASS = 0, 1
+FORM_AUTO, FORM_LANE_PER_AGE, FORM_QUAD = 0, 1, 2
 
 
 def mh_create(lib, ctx, chains: int, iterations: int, x0: np.ndarray, cov0: np.ndarray, reg_eps: float = 1e-6,
@@ -78,7 +79,7 @@ def mh_create(lib, ctx, chains: int, iterations: int, x0: np.ndarray, cov0: np.n
 
 EXPORTED_SYMBOLS = (
     "sepaihrd_create", "sepaihrd_destroy", "sepaihrd_last_error", "sepaihrd_abi_version",
-    "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_set_precision", "sepaihrd_eval_batch",
+    "sepaihrd_set_constraint_mode", "sepaihrd_set_arith", "sepaihrd_set_precision", "sepaihrd_set_integrator_form", "sepaihrd_eval_batch",
     "sepaihrd_eval_batch_device", "sepaihrd_eval_batch_begin", "sepaihrd_eval_batch_end", "sepaihrd_apply_constraints", "sepaihrd_get_kernel_info", "sepaihrd_get_kernel_info_for_batch", "sepaihrd_reserve",
     "sepaihrd_set_timing", "sepaihrd_get_timing", "sepaihrd_set_initial_state_mode",
     "sepaihrd_ensemble_quantiles", "sepaihrd_mh_create", "sepaihrd_mh_destroy", "sepaihrd_mh_evaluate_current",
@@ -123,6 +124,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_set_constraint_mode.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_arith.argtypes = [vp, C.c_int]
     lib.sepaihrd_set_precision.argtypes = [vp, C.c_int]
+    lib.sepaihrd_set_integrator_form.argtypes = [vp, C.c_int]
     lib.sepaihrd_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_eval_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_apply_constraints.argtypes = [vp, C.c_int, vp, C.c_int, vp]
@@ -238,6 +240,10 @@ class HipObjective:
     def set_precision(self, precision: int):
         """PRECISION_F64 (reference arithmetic) or PRECISION_F32 (fp32 state, fp64 likelihood: BASELINE configs[4])."""
         self._check(self.lib.sepaihrd_set_precision(self.ctx, int(precision)), "set_precision")
+
+    def set_integrator_form(self, form: int):
+        """FORM_AUTO (by batch size), FORM_LANE_PER_AGE or FORM_QUAD (sixteen lanes per chain): same bits either way."""
+        self._check(self.lib.sepaihrd_set_integrator_form(self.ctx, int(form)), "set_integrator_form")
 
     def calculate(self, theta) -> float:
         return float(self.eval_batch(np.asarray(theta, dtype=np.float64)[None, :])["loglik"][0])

@@ -141,6 +141,9 @@ public:
     double calculate(const Eigen::VectorXd& parameters) const override;
     const std::vector<std::string>& getParameterNames() const override;
     void calculateBatch(const double* thetas, int B, double* out, int* status = nullptr) const override;
+    // the SimulationException a per-chain status >= SEPAIHRD_STATUS_STEP_FAILURE stands for (2 odeint's 500 rejections,
+    // 3 step-attempt budget, 4 hand-off between wavefronts timed out); never returns
+    [[noreturn]] static void throwIntegrationFailure(int status);
     // per-chain step counters of the last calculateBatch (diagnostics)
     const std::vector<int32_t>& lastAccepted() const { return n_acc_; }
     const std::vector<int32_t>& lastRejected() const { return n_rej_; }

@@ -477,13 +477,31 @@ void HipSEPAIHRDObjectiveFunction::calculateBatch(const double* thetas, int B, d
     status_.resize(static_cast<size_t>(B)); n_acc_.resize(static_cast<size_t>(B)); n_rej_.resize(static_cast<size_t>(B));
     const int rc = sepaihrd_eval_batch(ctx_, thetas, B, out, status_.data(), n_acc_.data(), n_rej_.data(), nullptr, nullptr);
     if (rc != SEPAIHRD_OK) throw ModelException("SEPAIHRDObjectiveFunction::calculateBatch", sepaihrd_last_error(ctx_));
-    bool integration_failed = false;
+    int worst = 0;
     for (int b = 0; b < B; ++b) {
         if (status) status[b] = status_[static_cast<size_t>(b)];
-        if (status_[static_cast<size_t>(b)] >= SEPAIHRD_STATUS_STEP_FAILURE) integration_failed = true;
+        worst = std::max(worst, static_cast<int>(status_[static_cast<size_t>(b)]));
     }
-    if (integration_failed && !status)
-        throw SimulationException("Dopri5SolverStrategy::integrate", "Boost.Odeint integration failed: step size adjustment");
+    if (worst >= SEPAIHRD_STATUS_STEP_FAILURE && !status) throwIntegrationFailure(worst);
+}
+
+// Per-chain status >= 2: the evaluation produced no value.  The reference lets the solver's exception leave calculate()
+// (no try/catch around Simulator::run, SEPAIHRDObjectiveFunction.cpp:165; Dopri5SolverStrategy.cpp:38-42 rethrows
+// odeint's as SimulationException) and the samplers' safeEvaluate turns it into -1e18; same exception type here, the
+// message says which of the three causes it was.
+void HipSEPAIHRDObjectiveFunction::throwIntegrationFailure(int status) {
+    switch (status) {
+        case SEPAIHRD_STATUS_STEP_FAILURE:
+            throw SimulationException("Dopri5SolverStrategy::integrate", "Boost.Odeint integration failed: step size adjustment");
+        case SEPAIHRD_STATUS_STEP_BUDGET:
+            throw SimulationException("HipSEPAIHRDObjectiveFunction", "integration stopped: step-attempt budget exhausted (SEPAIHRD_STATUS_STEP_BUDGET)");
+        case SEPAIHRD_STATUS_PIPELINE:
+            throw SimulationException("HipSEPAIHRDObjectiveFunction",
+                                      "no value: the hand-off between the integrating wavefront and its likelihood wavefront timed out "
+                                      "(SEPAIHRD_STATUS_PIPELINE)");
+        default:
+            throw SimulationException("HipSEPAIHRDObjectiveFunction", "evaluation failed with per-chain status " + std::to_string(status));
+    }
 }
 
 double HipSEPAIHRDObjectiveFunction::calculate(const Eigen::VectorXd& parameters) const {
@@ -620,8 +638,7 @@ double HipSEPAIHRDGradientObjectiveFunction::evaluate_with_gradient(const Eigen:
             // -inf, then mapped to lowest() (:148-155); the simulation result is not used
             fp = LOWEST;
         } else {
-            if (status[u] >= SEPAIHRD_STATUS_STEP_FAILURE)
-                throw SimulationException("Dopri5SolverStrategy::integrate", "Boost.Odeint integration failed: step size adjustment");
+            if (status[u] >= SEPAIHRD_STATUS_STEP_FAILURE) throwIntegrationFailure(status[u]);
             fp = f_plus[u];  // status 1 with a valid state: non-finite likelihood, already lowest()
         }
         grad[i] = std::isfinite(fp) ? (fp - f_center) / eps[u] : 0.0;  // :163-167

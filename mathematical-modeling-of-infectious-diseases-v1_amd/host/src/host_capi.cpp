@@ -55,6 +55,22 @@ const char* host_last_error(void) { return g_error.c_str(); }
 // iteration loop of this thread's last device-resident sampler run, without set-up and read-back (seconds)
 double host_last_mh_loop_seconds(void) { return g_last_mh_loop_seconds; }
 
+// Test hook (no GPU needed): what the adapter raises for a per-chain status >= 2.  Returns 1 when it is the
+// SimulationException the reference's solver wrapper throws (Dopri5SolverStrategy.cpp:38-42), 0 for any other type;
+// the message goes to host_last_error.
+int host_status_exception(int status) {
+    try {
+        HipSEPAIHRDObjectiveFunction::throwIntegrationFailure(status);
+    } catch (const SimulationException& e) {
+        g_error = e.what();
+        return 1;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 0;
+    }
+    return 0;
+}
+
 // names / npi_names: '\n'-joined; sigmas: [P].  Bounds come from pb->lower/upper.
 // with_objective = 0 builds the parameter manager only (no device needed)
 void* host_objective_create(const sepaihrd_problem* pb, const char* names, const char* npi_names,

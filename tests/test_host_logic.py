@@ -419,3 +419,27 @@ def test_post_calibration_tree_matches_the_reference_writers_and_its_plot_script
     lines = open(trace).read().splitlines()
     assert lines[0].split(",") == want["posterior_trace"]["header"]
     assert lines[1].split(",")[:2] == ["0", "-1.500000e+06"] and lines[3].split(",")[1] == "3.250000e-03"
+
+
+def test_adapter_maps_every_failure_status_to_the_references_exception(mm):
+    """Per-chain status 2 (odeint's 500 rejections), 3 (attempt budget) and 4 (SEPAIHRD_STATUS_PIPELINE: the hand-off
+    between the integrating wavefront and its likelihood wavefront timed out) all leave calculate() as the
+    SimulationException the reference's solver wrapper throws (Dopri5SolverStrategy.cpp:38-42), which the samplers'
+    safeEvaluate turns into -1e18 (MetropolisHastingsSampler.cpp:65-74); the header declares all three."""
+    header = open(os.path.join(ROOT, "include", "sepaihrd_hip.h")).read()
+    declared = dict((name, int(v)) for name, v in re.findall(r"#define (SEPAIHRD_STATUS_[A-Z_]+) (\d+)", header))
+    assert declared == {"SEPAIHRD_STATUS_OK": 0, "SEPAIHRD_STATUS_INVALID": 1, "SEPAIHRD_STATUS_STEP_FAILURE": 2,
+                        "SEPAIHRD_STATUS_STEP_BUDGET": 3, "SEPAIHRD_STATUS_PIPELINE": 4}
+    lib = mm.hostabi.load_library()
+    lib.host_status_exception.argtypes = [ctypes.c_int]
+    lib.host_last_error.restype = ctypes.c_char_p
+    seen = set()
+    for name, status in declared.items():
+        if status < 2:
+            continue
+        assert lib.host_status_exception(status) == 1
+        msg = lib.host_last_error().decode()
+        assert msg and msg not in seen
+        seen.add(msg)
+        if status >= 3:
+            assert name in msg

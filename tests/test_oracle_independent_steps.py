@@ -151,3 +151,90 @@ def test_step_decrease_rule(oracle_py, ref_fixture, solver):
     for delta, want in ((dt_red * (1 - 1e-9), 3), (dt_red * (1 + 1e-9), 4)):
         acc, rej = _accepts(oracle_py, ref_fixture, solver, tol, [0.0, h, h + delta], dt_hint=h)
         assert (acc, rej) == (want, 1), (delta, acc, rej)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integrate_times itself -- the loop around the controlled stepper -- written a second time, here, sharing no code
+# with oracle/: Boost.Odeint's integrate_times for a controlled stepper
+#   loop: t = *times++; observer(x, t); while (t_next - t > eps): cur = min(dt, t_next - t);
+#         try_step(x, t, cur) == success ? dt = max(dt, cur) : dt = cur          (cur is updated by try_step)
+# i.e. no step crosses an output time, dt never shrinks on success, the time restarts from the grid value at every
+# output, the FSAL derivative of Dormand-Prince is carried over outputs AND over beta / kappa breakpoints (the derivative
+# at t = breakpoint is evaluated with the period that ends there), Cash-Karp evaluates f(x, t) afresh at every attempt.
+# Stage arithmetic: SciPy's rk_step / the generic step above (a different association than odeint's, so values agree to
+# rounding and accept decisions agree unless an error value sits within ~1e-13 of 1 -- none does here).
+# ---------------------------------------------------------------------------------------------------------------
+def _integrate_times_second_author(f, y0, times, dt, tol, solver):
+    from scipy.integrate._ivp import rk
+    eps = np.finfo(np.float64).eps
+    y = np.array(y0, dtype=np.float64)
+    states, counts, sizes = [y.copy()], [], []
+    dxdt = None                      # FSAL derivative (Dormand-Prince only), initialised at the first attempt
+    for k in range(len(times) - 1):
+        t, t_next = float(times[k]), float(times[k + 1])
+        acc = rej = 0
+        while t_next - t > eps:
+            cur = min(dt, t_next - t)
+            if solver == 0:
+                if dxdt is None:
+                    dxdt = f(t, y)
+                K = np.empty((rk.RK45.n_stages + 1, y.size))
+                y_new, f_new = rk.rk_step(f, t, y, dxdt, cur, rk.RK45.A, rk.RK45.B, rk.RK45.C, K)
+                err = (K.T @ rk.RK45.E) * cur
+                d0 = dxdt
+            else:
+                d0 = f(t, y)
+                y_new, K = _rk_step(f, t, y, cur, CK_A, CK_B5, CK_C)
+                err = cur * sum(float(b5 - b4) * kk for b5, b4, kk in zip(CK_B5, CK_B4, K))
+            value = np.max(np.abs(err) / (tol + tol * (np.abs(y) + cur * np.abs(d0))))
+            if value > 1.0:
+                rej += 1
+                dt = cur * max(0.9 * value ** (-1.0 / 3.0), 0.2)
+                continue
+            t += cur
+            y = y_new
+            if solver == 0:
+                dxdt = f_new
+            acc += 1
+            sizes.append(cur)
+            grown = cur
+            if value < 0.5:
+                grown = cur * 0.9 * max(5.0 ** -5, value) ** (-1.0 / 5.0)
+            dt = max(dt, grown)
+        states.append(y.copy())
+        counts.append((acc, rej))
+    return np.array(states), counts, sizes
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("tol,stride", [(1e-6, 1.0), (1e-9, 1.0), (1e-7, 2.5)])
+def test_integrate_times_loop_against_a_second_implementation(oracle_py, ref_fixture, solver, tol, stride):
+    """30 output intervals across the kappa breakpoint at t = 13 (and, with stride 2.5, the one at 63): accepted and
+    rejected attempts PER INTERVAL (the oracle run on every prefix of the grid) and the states at every output against
+    the second implementation above, both steppers, tolerances that make the controller reject (1e-9) and grow steps
+    across outputs, and a non-integer stride (the remainder of an interval after a rejected step, the time restarting
+    from the grid value)."""
+    times = stride * np.arange(31.0)
+    n_obs = len(times)
+    obs = np.zeros((n_obs, ref_fixture.n))
+    q = ref_fixture.with_(times=times, solver=solver, abs_err=tol, rel_err=tol, dt_hint=1.0, obs_H=obs, obs_ICU=obs, obs_D=obs)
+    theta = np.asarray(q.base_theta)
+    orc = oracle_py.Oracle(q)
+    full = orc.eval_batch(theta[None, :], want_traj=True, nthreads=1)
+    assert full["status"][0] == 0
+    f = lambda t, y: orc.rhs(y, t, theta)
+    states, counts, sizes = _integrate_times_second_author(f, full["traj"][0, 0], times, 1.0, tol, solver)
+    # per-interval counts of the oracle: the integration up to output k does not depend on later outputs
+    cum = [(0, 0)]
+    for k in range(1, len(times)):
+        qk = q.with_(times=times[:k + 1], obs_H=obs[:k + 1], obs_ICU=obs[:k + 1], obs_D=obs[:k + 1])
+        r = oracle_py.Oracle(qk).eval_batch(theta[None, :], nthreads=1)
+        cum.append((int(r["n_accept"][0]), int(r["n_reject"][0])))
+    per_interval = [(a1 - a0, r1 - r0) for (a0, r0), (a1, r1) in zip(cum[:-1], cum[1:])]
+    assert per_interval == counts
+    assert cum[-1] == (int(full["n_accept"][0]), int(full["n_reject"][0]))
+    assert sum(r for _, r in counts) > 0 or tol >= 1e-6          # the tight tolerance makes the controller reject
+    assert max(a for a, _ in counts) > 1                         # some interval needs more than one step
+    rel = np.abs(full["traj"][0] - states) / np.maximum(np.abs(states), 1.0)
+    assert rel.max() < 1e-11, rel.max()
+    assert len(sizes) == cum[-1][0]

@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""Diagnostic: the same chains through the 4-lane and the 16-lane kernel (two processes: the switch is read once).
+"""The same chains through both forms of the fp64 integrator (sepaihrd_set_integrator_form), every output array compared bit for bit;
+with tools/libsepaihrd_hip_experiments.so present also through its one-wavefront-per-chain kernel.
 usage: compare_lane_split.py [--solver 0|1] [--chains N]"""
 import argparse, json, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def child(args):
-    sys.path.insert(0, ROOT)
-    import mmid_amd_loader
-    mm = mmid_amd_loader.load()
+def evaluate(mm, args, form, fma_lib_wave_chain=False):
+    """the batch (or the fuzz cases) through one form of the integrator; returns {name: array}"""
     pb = mm.SEPAIHRDProblem.load(os.path.join(ROOT, "tests", "golden", args.problem)).with_(
         solver=args.solver, arith=mm.ARITH_FMA if args.arith == "fma" else mm.ARITH_STRICT)
     if args.one_step:
         times = np.array([0.0, args.one_step])
         pb = pb.with_(times=times, obs_H=pb.obs_H[:2], obs_ICU=pb.obs_ICU[:2], obs_D=pb.obs_D[:2])
+
+    def run(q, th):
+        hip = mm.HipObjective(q)
+        if form is not None:
+            hip.set_integrator_form(form)
+        return hip.eval_batch(th, want_traj=True)
+
     rng = np.random.default_rng(1)
     if args.fuzz:
-        # random variants of the problem, the same in both processes: age classes 3 or 4 (3 pads a lane), output grids
+        # random variants of the problem, the same for every form: age classes 3 or 4 (3 pads a lane), output grids
         # of random length and stride (steps that stop at odd places), tolerances, attempt budgets that cut chains
         # short, both constraint modes, wide parameter draws (some invalid), ragged batch sizes
         res = {}
@@ -42,15 +48,23 @@ def child(args):
             wide = frng.random() < 0.5
             th = (lo + (hi - lo) * frng.uniform(-0.1, 1.1, (B, q.n_params))) if wide else \
                 np.asarray(q.base_theta)[None, :] * (1 + 0.05 * frng.standard_normal((B, q.n_params)))
-            r = mm.HipObjective(q).eval_batch(th, want_traj=True)
+            r = run(q, th)
             for k, a in r.items():
                 if isinstance(a, np.ndarray):
                     res[f"case{v}_{k}"] = a
-        np.savez(args.out, **res)
-        return
+        return res
     theta = pb.base_theta[None, :] * (1 + 0.02 * rng.standard_normal((args.chains, pb.n_params)))
-    r = mm.HipObjective(pb).eval_batch(theta, want_traj=True)
-    np.savez(args.out, **{k: v for k, v in r.items() if isinstance(v, np.ndarray)})
+    r = run(pb, theta)
+    return {k: v for k, v in r.items() if isinstance(v, np.ndarray)}
+
+
+def child(args):
+    """the experiment build's one-wavefront-per-chain kernel (own process: SEPAIHRD_HIP_LIB and the switch are read once)"""
+    sys.path.insert(0, ROOT)
+    import mmid_amd_loader
+    mm = mmid_amd_loader.load()
+    np.savez(args.out, **evaluate(mm, args, None))
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -66,20 +80,25 @@ if __name__ == "__main__":
     if a.out:
         child(a)
         sys.exit(0)
-    outs = []
-    # 4-lane kernel, 16-lane form, and (tolerance build only) the one-wavefront-per-chain form
-    variants = [("0", "0"), ("1", "0")] + ([("1", "2")] if a.arith == "fma" else [])
-    for mode, wave in variants:
-        out = f"/tmp/lane_split_{mode}{wave}.npz"
-        env = dict(os.environ, SEPAIHRD_LANE_SPLIT=mode, SEPAIHRD_WAVE_CHAIN=wave)
+    sys.path.insert(0, ROOT)
+    import mmid_amd_loader
+    mm = mmid_amd_loader.load()
+    # one lane per (chain, age) and the sixteen-lanes-per-chain form of the shipped library, forced through the C ABI
+    outs = [evaluate(mm, a, mm.hipabi.FORM_LANE_PER_AGE), evaluate(mm, a, mm.hipabi.FORM_QUAD)]
+    # the one-wavefront-per-chain kernel exists in the experiment build only (csrc/Makefile `experiments`)
+    exp_lib = os.path.join(ROOT, "tools", "libsepaihrd_hip_experiments.so")
+    if a.arith == "fma" and os.path.exists(exp_lib):
+        out = "/tmp/lane_split_wave_chain.npz"
+        env = dict(os.environ, SEPAIHRD_HIP_LIB=exp_lib, SEPAIHRD_WAVE_CHAIN="2")
         subprocess.run([sys.executable, __file__, "--solver", str(a.solver), "--chains", str(a.chains), "--out", out, "--problem", a.problem, "--arith", a.arith, "--fuzz", str(a.fuzz), "--fuzz-cases", str(a.fuzz_cases),
                         "--one-step", str(a.one_step)],
                        env=env, check=True)
-        outs.append(np.load(out))
+        loaded = np.load(out)
+        outs.append({k: loaded[k] for k in loaded.files})
     all_same = True
     for other in range(1, len(outs)):
         tag = "16-lane" if other == 1 else "wave-per-chain"
-        for k in outs[0].files:
+        for k in outs[0]:
             x, y = outs[0][k], outs[other][k]
             if k.endswith("traj"):  # rows after the point where a chain stopped (status != 0) are never written
                 ok = outs[0][k[:-4] + "status"] == 0
@@ -105,7 +124,7 @@ if __name__ == "__main__":
                     print("  comp", c, "differing", int(dd.sum()), "of", dd.size, "n_accept", outs[0]["n_accept"][:4])
                 print("chain", ch, "values", x[ch, tfirst, d[ch, tfirst]][:6], y[ch, tfirst, d[ch, tfirst]][:6])
     if a.fuzz:
-        st = np.concatenate([outs[0][k] for k in outs[0].files if k.endswith("_status")])
+        st = np.concatenate([outs[0][k] for k in outs[0] if k.endswith("_status")])
         print(f"fuzz seed {a.fuzz}: {a.fuzz_cases} problem variants, {st.size} chains, status counts {np.bincount(st, minlength=4).tolist()}, "
               f"all arrays identical={all_same}")
     sys.exit(0 if all_same else 1)
