@@ -37,7 +37,8 @@ PARITY_NOTES = {
               "(test_headline_batch_matches_oracle_chain_by_chain, test_multichain_mh_matches_oracle_sampler)",
     "fma": "contraction + folded constants + hardware log2/exp2 in the step-size factor: states <= 1e-6 (north-star "
            "tolerance; measured 1e-11), log-likelihood <= 1e-7; MH accept traces equal to the strict oracle's for the "
-           "tested seeds (test_device_sampler_accept_traces_in_production_arithmetic) but not guaranteed bit-exact",
+           "tested seeds (4096 chains x 300 iterations: test_headline_batch_accept_traces_in_production_arithmetic; this "
+           "run's own count: sampler_pipeline.accept_trace_mismatches_vs_strict) but not guaranteed bit-exact",
 }
 
 
@@ -61,6 +62,9 @@ def parse_args():
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
     ap.add_argument("--sampler-iterations", type=int, default=400,
                     help="informational Adaptive-Metropolis run around the kernel after the timed region (0 = skip)")
+    ap.add_argument("--sampler-long-iterations", type=int, default=100000,
+                    help="one more such run at the reference's own settings (data/configuration/mcmc_settings.txt: 100 000 "
+                         "iterations, burn-in 5 000, adaptation_period 100, thinning 100): about a minute (0 = skip)")
     return ap.parse_args()
 
 
@@ -152,28 +156,31 @@ def cpu_baseline(pb, theta, budget_s):
     }
 
 
-def sampler_pipeline(mm, pb, theta, iterations=None):
+def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=None):
     """Informational, outside the timed region: the whole Adaptive-Metropolis iteration around the kernel
-    (host random streams + accept test, device-resident proposal / adaptation state, one evaluation per
-    chain and iteration), proposals per second for the step's chains.  Two runs of different length separate the
-    steady-state iteration (the slope) from the set-up and read-back of a run (history allocation, covariance
-    read-back).  None if the host library is absent."""
+    (host random streams, device-resident proposal / adaptation state and accept test, one evaluation per chain and
+    iteration), proposals per second for the step's chains.
+      * a short run (`iterations`): the iteration loop as the host library times it, MEDIAN of three runs, the better of
+        one and two chain groups; the same run in strict arithmetic gives accept_trace_mismatches_vs_strict -- the
+        acceptance contract of the arithmetic `value` is measured in, counted on this run's own chains;
+      * a run at the reference's own settings (`long_iterations`, burn-in 5 000, adaptation_period 100, thinning 100):
+        the covariance refresh is O(P^2) from running co-moments, so the iteration must not slow down as the chain
+        grows -- reported against the bare evaluation step.
+    None if the host library is absent."""
     try:
         iters = int(iterations or 120)
         host = mm.HostObjective(pb)
         host.metropolis_hastings(theta[:16], 1, 4, 1, device_state=True)
+        kw = dict(burn_in=iters // 3, adaptation_period=max(10, iters // 4), thinning=iters)
 
-        def slope(run):
-            # the iteration loop as the host library times it (set-up and read-back of the run excluded); the host side
-            # shares the box with other tenants: the best of three runs
-            short = 0
-            (dt, r) = min((run(iters) for _ in range(3)), key=lambda p: p[1]["loop_seconds"])
-            steady = r["loop_seconds"] / (iters - 1)
-            return steady, dt, r, short
+        def median_of_three(run):
+            runs = sorted((run(iters) for _ in range(3)), key=lambda p: p[1]["loop_seconds"])
+            dt, r = runs[1]
+            return r["loop_seconds"] / (iters - 1), dt, r
 
         def run_one(n):
             t0 = time.perf_counter()
-            r = host.metropolis_hastings(theta, 1, n, n // 3, adaptation_period=max(10, n // 4), thinning=n, device_state=True)
+            r = host.metropolis_hastings(theta, 1, n, device_state=True, **kw)
             return time.perf_counter() - t0, r
         # two groups of chains, each with its own context, stream and host thread: while one group's evaluation runs
         # the other group's accept test and draws are made (same chains, same results: chain c draws from mt19937(1 + c))
@@ -182,20 +189,42 @@ def sampler_pipeline(mm, pb, theta, iterations=None):
 
         def run_two(n):
             t0 = time.perf_counter()
-            r = mm.hostabi.metropolis_hastings_groups(pair, theta, 1, n, n // 3, adaptation_period=max(10, n // 4), thinning=n)
+            r = mm.hostabi.metropolis_hastings_groups(pair, theta, 1, n, **kw)
             return time.perf_counter() - t0, r
-        s1, dt1, r1, short = slope(run_one)
-        s2, dt2, r2, _ = slope(run_two)
+        s1, dt1, r1 = median_of_three(run_one)
+        s2, dt2, r2 = median_of_three(run_two)
         same = bool(np.array_equal(r1["accept_trace"], r2["accept_trace"]))
         steady, dt, r, groups = (s2, dt2, r2, 2) if s2 < s1 else (s1, dt1, r1, 1)
-        return {"proposals_per_s": theta.shape[0] / steady, "ms_per_iteration": steady * 1e3, "chain_groups": groups,
-                "ms_per_iteration_by_groups": {"1": s1 * 1e3, "2": s2 * 1e3}, "groups_give_identical_accept_traces": same,
-                "ms_per_iteration_incl_setup": dt / (iters - 1) * 1e3, "setup_and_readback_ms": max(0.0, (dt - steady * (iters - 1)) * 1e3),
-                "chains": int(theta.shape[0]), "iterations": iters,
-                "acceptance": float(r["accepted"].mean() / (iters - 1)),
-                "note": "ms_per_iteration = the iteration loop of a %d-iteration run timed inside the host library (best of three runs; the run's "
-                        "set-up and read-back are reported separately), the better of one and two chain groups; sampler state resident in HBM, "
-                        "host keeps the mt19937 streams (DESIGN.md 6c)" % iters}
+        out = {"proposals_per_s": theta.shape[0] / steady, "ms_per_iteration": steady * 1e3, "chain_groups": groups,
+               "ms_per_iteration_by_groups": {"1": s1 * 1e3, "2": s2 * 1e3}, "groups_give_identical_accept_traces": same,
+               "ms_per_iteration_incl_setup": dt / (iters - 1) * 1e3, "setup_and_readback_ms": max(0.0, (dt - steady * (iters - 1)) * 1e3),
+               "chains": int(theta.shape[0]), "iterations": iters, "covariance_refreshes_in_run": int(sum(1 for t in range(kw["burn_in"] + 1, iters) if t % kw["adaptation_period"] == 0)),
+               "acceptance": float(r["accepted"].mean() / (iters - 1)),
+               "note": "ms_per_iteration = the iteration loop of a %d-iteration run timed inside the host library (median of three runs; the run's "
+                       "set-up and read-back are reported separately), the better of one and two chain groups; sampler state resident in HBM, "
+                       "host keeps the mt19937 streams (DESIGN.md 6c)" % iters}
+        if pb.arith == mm.ARITH_FMA:
+            strict = mm.HostObjective(pb.with_(arith=mm.ARITH_STRICT)).metropolis_hastings(theta, 1, iters, device_state=True, **kw)
+            diff = strict["accept_trace"] != r1["accept_trace"]
+            out["accept_trace_mismatches_vs_strict"] = int(diff.sum())
+            out["accept_trace_decisions_compared"] = int(diff.size)
+            out["chains_with_a_mismatch"] = int(diff.any(axis=1).sum())
+        if long_iterations and long_iterations > 1:
+            n = int(long_iterations)
+            t0 = time.perf_counter()
+            rl = host.metropolis_hastings(theta, 1, n, min(5000, n // 3), adaptation_period=100, thinning=100, device_state=True,
+                                          want_trace=False)
+            wall = time.perf_counter() - t0
+            ms = rl["loop_seconds"] / (n - 1) * 1e3
+            out["long_run"] = {"iterations": n, "burn_in": min(5000, n // 3), "adaptation_period": 100, "thinning": 100,
+                               "ms_per_iteration": ms, "proposals_per_s": theta.shape[0] * (n - 1) / rl["loop_seconds"],
+                               "loop_seconds": rl["loop_seconds"], "wall_seconds": wall,
+                               "vs_ms_per_step": (ms / step_ms) if step_ms else None,
+                               "samples_per_chain": int(rl["samples"].shape[1]),
+                               "acceptance": float(rl["accepted"].mean() / (n - 1)),
+                               "note": "the reference's own run length (data/configuration/mcmc_settings.txt); covariance refresh from "
+                                       "running co-moments, O(P^2) per refresh whatever the chain length; one chain group"}
+        return out
     except Exception as e:  # informational only
         return {"error": str(e)[:200]}
 
@@ -260,9 +289,6 @@ def main():
     for i in range(W):
         step(i)
     torch.cuda.synchronize(dev)
-    # HIP events around the integrator kernel and the likelihood pass, on the launch stream, for every 8th step of the
-    # timed region (three event records per step cost 2.4 % of a 4096-chain step)
-    hip.set_timing(8 if K >= 16 else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -278,6 +304,14 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     step_ms = ev0.elapsed_time(ev1) / max(K, 1)
+    # The dominant kernel's own duration: a SECOND pass of the same K steps, outside the timed region, with HIP events
+    # on the launch stream around the integrator kernel and the likelihood pass of EVERY launch (the records cost ~15 us of
+    # stream time per launch, which is why they are not in the timed pass: the kernel time is what they bracket, not
+    # what they cost).  roofline.achieved divides by this; roofline.frac_of_step divides by ms_per_step instead.
+    hip.set_timing(1)
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize(dev)
     tm = hip.get_timing()
     hip.set_timing(False)
     kernel_ms = tm["integrator_ms"] / max(tm["launches"], 1)      # dominant kernel: sepaihrd_eval_kernel
@@ -311,6 +345,7 @@ def main():
     torch.cuda.synchronize(dev)
     other_wall_ms = (time.perf_counter() - t_other) * 1e3 / n_other
     other_ms = e0.elapsed_time(e1) / n_other
+    strict_wall_ms = other_wall_ms if other == "strict" else (elapsed / max(K, 1) * 1e3 if args.arith == "strict" and args.precision == "f64" else None)
     hip.set_arith(pb.arith)
     hip.set_precision(pb.precision)
 
@@ -344,11 +379,7 @@ def main():
         value = evals_total / elapsed_max
         info = hip.kernel_info(B)
         bytes_eval = 8 * P + 16 + problem_bytes(pb) / B        # theta in, loglik + counters out
-        # csrc/sepaihrd_device.h split_likelihood(): batches that do not fill the chip, and Dopri5 in tolerance mode at
-        # any size, park the daily increments for a separate likelihood pass
-        waves4 = -(-B // (64 // max(1, 1 << (pb.n - 1).bit_length())))
-        split_ll = ((waves4 <= 1024 or (args.arith == "fma" and pb.solver == 0)) and args.precision == "f64"
-                    and "+ll" not in info["kernel_name"])  # "+ll": likelihood on consumer waves of the integrator's workgroup, nothing parked
+        split_ll = info.get("likelihood_form", 0) == 1 and args.precision == "f64"  # SEPAIHRD_LL_SEPARATE_PASS: increments parked in HBM
         ws_bytes_eval = pb.n_times * 3 * pb.n * 8 if split_ll else 0
         bytes_launch = bytes_eval * B
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
@@ -369,6 +400,8 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed_max / max(K, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
+            # the bit-exact-contract arithmetic on the same draws over the same number of steps (config.parity_mode)
+            "value_strict": (world * B / (strict_wall_ms * 1e-3)) if strict_wall_ms else None,
             "config": {
                 "workload": f"BASELINE {args.workload}: SEPAIHRD {pb.n} age groups, {solver_name}, "
                             f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
@@ -388,6 +421,9 @@ def main():
                 "bound": "fp64_valu" if args.precision == "f64" else "fp32_valu", "achieved": fp64_tflops,
                 "peak": FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": fp64_tflops / (FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS),
+                "frac_of_step": flops_eval * B / (elapsed_max / max(K, 1)) / 1e12 / (FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS),
+                "kernel_ms_source": "HIP events around every launch of a second, untimed pass of the same %d steps" % K,
+                "likelihood_form": {0: "inline", 1: "separate pass over parked increments", 2: "consumer waves of the integrator's workgroup"}.get(info.get("likelihood_form", 0)),
                 "algorithmic_flops_per_eval": flops_eval,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": ("profile (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this "
@@ -421,7 +457,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pb, pools_host[0], args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        out["sampler_pipeline"] = sampler_pipeline(mm, pb, pools_host[0], args.sampler_iterations) if world == 1 and args.sampler_iterations > 1 else None
+        out["sampler_pipeline"] = (sampler_pipeline(mm, pb, pools_host[0], args.sampler_iterations,
+                                                    args.sampler_long_iterations if args.workload == "c1" else 0, out["ms_per_step"])
+                                   if world == 1 and args.sampler_iterations > 1 else None)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -402,6 +402,9 @@ int sepaihrd_mh_history_length(const sepaihrd_mh *mh);
 int sepaihrd_apply_constraints(const sepaihrd_ctx *ctx, int mode, const double *in, int B, double *out);
 
 /* Launch geometry / resource report of the evaluation kernel the ctx will use. */
+#define SEPAIHRD_LL_INLINE 0          /* three logs per output inside the integrating wave; nothing parked */
+#define SEPAIHRD_LL_SEPARATE_PASS 1   /* daily increments parked in the ctx workspace (T 3 n 8 B per evaluation), two kernels after */
+#define SEPAIHRD_LL_CONSUMER_WAVES 2  /* a second wave of the integrator's SIMD, fed through LDS; nothing parked */
 typedef struct sepaihrd_kernel_info {
     int32_t lanes_per_chain;   /* n rounded up to a power of two */
     int32_t chains_per_wave;
@@ -409,6 +412,7 @@ typedef struct sepaihrd_kernel_info {
     int32_t vgprs, sgprs, lds_bytes, scratch_bytes;
     int32_t max_blocks_per_cu; /* occupancy query */
     int32_t num_cus;
+    int32_t likelihood_form;   /* SEPAIHRD_LL_*: where the Poisson terms of such a launch are evaluated */
     char kernel_name[128];
     char device_name[128];
 } sepaihrd_kernel_info;

@@ -869,6 +869,7 @@ int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx* ctx, int32_t batch_chains, 
     info->vgprs = li.vgprs; info->sgprs = li.sgprs; info->scratch_bytes = li.scratch;
     info->lds_bytes = li.lds_static + (int)eval_lds_bytes(ctx->dp);
     info->max_blocks_per_cu = li.max_blocks_per_cu;
+    info->likelihood_form = li.likelihood_form;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device), ctx, return SEPAIHRD_E_HIP);
     info->num_cus = prop.multiProcessorCount;

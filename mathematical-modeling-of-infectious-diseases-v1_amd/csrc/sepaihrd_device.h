@@ -74,9 +74,12 @@ struct EvalOutputs {
 inline size_t workspace_cum_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains * pb.lpc; }
 inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains; }
 
+// sepaihrd_kernel_info::likelihood_form (include/sepaihrd_hip.h: SEPAIHRD_LL_*)
+constexpr int LL_FORM_INLINE = 0, LL_FORM_SEPARATE_PASS = 1, LL_FORM_CONSUMER_WAVES = 2;
 struct LaunchInfo {
     int vgprs, sgprs, lds_static, scratch, max_blocks_per_cu;
     int lanes_per_chain;  // of the kernel a launch of the given batch uses
+    int likelihood_form;  // LL_FORM_*: inline in the integrator, separate pass over parked increments, consumer waves
     const char* name;
 };
 
@@ -140,13 +143,10 @@ inline int lanes_per_chain(int n) {
 constexpr int MAX_TIMES = 12288;  // output grid staged in LDS (96 KiB at the cap)
 constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;  // LDS-DMA landing zone of the inline-likelihood build
 constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is always used
-// Which form of the likelihood a launch of `waves` wavefronts uses.  Up to one wave per SIMD the chip is not
-// full and the separate pass always wins.  Beyond that it still wins for Dopri5 in fma arithmetic, whose
-// integrator without the inline logs fits 256 registers (two waves per SIMD, no spills: 14.9 M vs 13.9 M evals/s
-// at 32 768 chains); the other builds keep the logs inside the wave there.
-inline bool split_likelihood(int solver, bool arith_fma, size_t waves) {
-    return waves <= (size_t)SPLIT_LL_MAX_BLOCKS || (arith_fma && solver == 0);
-}
+// Which form of the likelihood a launch uses is decided in the kernel translation unit (split_pays in
+// csrc/sepaihrd_kernels.hip): up to one wave per SIMD the chip is not full and the separate pass always wins; beyond that it
+// wins only where the integrator WITHOUT the inline logs fits two waves per SIMD (Dopri5 in fma arithmetic up to 4 age
+// classes: 256 registers, 15.1 M vs 13.9 M evals/s at 32 768 chains) -- elsewhere the parked increments are pure traffic.
 #if defined(__HIPCC__)
 #define SEP_HOST_DEVICE __host__ __device__
 #else

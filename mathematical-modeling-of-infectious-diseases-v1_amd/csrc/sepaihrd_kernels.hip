@@ -1053,12 +1053,40 @@ inline int ll_serial_min_waves() {
     }();
     if (v >= 0) return v;
 #endif
-    return LL_SERIAL_MIN_WAVES;
+    // 16 lanes per chain (round 3, 1001 days): the walk takes 3.3 - 4.4 ms whatever the batch (one lane walks 16 ages x 1001
+    // days), the parallel kernel 1.3 / 2.5 / 5.0 ms at 8192 / 16 384 / 32 768 chains: they cross near 28 000 chains
+    return LPC >= 16 ? 1344 : LL_SERIAL_MIN_WAVES;
 }
 
 // ----------------------------------------------------------------------------------
 // launch plumbing
 // ----------------------------------------------------------------------------------
+// Does a launch of `blocks` wavefronts evaluate the likelihood as a separate pass over increments parked in HBM
+// (T 3 n 8 bytes per evaluation, written once and read once)?  Up to one wave per SIMD the chip is not full and the pass
+// always wins (three logs per output leave the serial critical path of every wave).  Beyond that it pays only where
+// the integrator without the inline logs gains a second wave per SIMD from it: its register count says so (<= 256:
+// Dopri5 in fma arithmetic with up to 4 age classes -- 15.1 M vs 13.9 M evals/s at 32 768 chains).  The 16-age
+// integrator needs 274 registers either way: parking bought it nothing and cost 12.6 GB written + read per 32 768-chain
+// step (22 % of the step in the pass that reads them back); it keeps its logs inline.
+template <int LPC, int SOLVER>
+inline bool split_pays(size_t blocks) {
+#ifdef SEPAIHRD_EXPERIMENTS
+    static const int forced = [] {
+        const char* e = getenv("SEPAIHRD_SPLIT_LL");
+        return e == nullptr ? -1 : atoi(e);
+    }();
+    if (forced >= 0 && blocks > (size_t)SPLIT_LL_MAX_BLOCKS) return forced != 0;
+#endif
+    if (blocks <= (size_t)SPLIT_LL_MAX_BLOCKS) return true;
+    if (!(SEPAIHRD_ARITH_FMA != 0 && SOLVER == 0)) return false;
+    static const bool second_wave = [] {
+        hipFuncAttributes attr;
+        return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>)) == hipSuccess &&
+               attr.numRegs <= 256;
+    }();
+    return second_wave;
+}
+
 template <int LPC, int SOLVER, int WPS, bool INLINE_LL>
 int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, const EvalOutputs& out, void* stream) {
     const size_t lds = eval_lds_bytes(pb);
@@ -1100,7 +1128,7 @@ int needs_workspace_one(const DevProblem& pb, int B, int force_split) {
         // the 16-lane form evaluates the likelihood on consumer waves of the same workgroup: no workspace
         if (lane_split_wanted(pb, B)) return (quad_fused_wanted() && !force_split && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS) ? 0 : 1;
     }
-    return (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || force_split) ? 1 : 0;
+    return (split_pays<LPC, SOLVER>((size_t)blocks) || force_split) ? 1 : 0;
 }
 
 template <int LPC, int SOLVER>
@@ -1117,7 +1145,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
         if (lane_split_wanted(pb, B)) return launch_quad<SOLVER>(pb, d_theta, B, out, stream);
     }
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
-    if (split_likelihood(SOLVER, SEPAIHRD_ARITH_FMA != 0, (size_t)blocks) || out.force_split)
+    if (split_pays<LPC, SOLVER>((size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
         // two waves per SIMD only pay when there are two waves for every SIMD
@@ -1127,8 +1155,9 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
 }
 
 template <typename K>
-int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const char* name, int block_threads = WAVE,
+int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const char* name, int ll_form, int block_threads = WAVE,
             size_t lds_bytes = 0) {
+    info->likelihood_form = ll_form;
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) return -3;
     info->vgprs = attr.numRegs;
@@ -1145,18 +1174,27 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
 
 template <int LPC, int SOLVER>
 int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name) {
+    constexpr int CPW = WAVE / LPC;
 #if SEPAIHRD_HAVE_WAVE_CHAIN
     if constexpr (LPC == 4) {
         if (batch > 0 && wave_chain_wanted(batch))
-            return info_of(&sepaihrd_eval_wave_kernel<SOLVER>, pb, WAVE, info, "sepaihrd_eval_wave_kernel[fma]", WAVE, wave_chain_lds_bytes(pb));
+            return info_of(&sepaihrd_eval_wave_kernel<SOLVER>, pb, WAVE, info, "sepaihrd_eval_wave_kernel[fma]", LL_FORM_SEPARATE_PASS, WAVE, wave_chain_lds_bytes(pb));
     }
 #endif
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(pb, batch))
-            return quad_fused_wanted() ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", 8 * WAVE, quad_fused_lds_bytes(pb))
-                                       : info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME);
+            return (quad_fused_wanted() && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS)
+                       ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", LL_FORM_CONSUMER_WAVES, 8 * WAVE, quad_fused_lds_bytes(pb))
+                       : info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME, LL_FORM_SEPARATE_PASS);
     }
-    return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name);
+    // the same branches as launch_one (batch <= 0: a batch that fills the chip)
+    const size_t blocks = batch > 0 ? (size_t)((batch + CPW - 1) / CPW) : (size_t)1 << 20;
+    if (split_pays<LPC, SOLVER>(blocks))
+        return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name, LL_FORM_SEPARATE_PASS);
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
+        if (blocks >= 2 * 1024) return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 2, true>, pb, LPC, info, name, LL_FORM_INLINE);
+    }
+    return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, true>, pb, LPC, info, name, LL_FORM_INLINE);
 }
 
 #define SEP_DISPATCH(FN, ...)                                                                  \

@@ -48,7 +48,7 @@ class sepaihrd_kernel_info(C.Structure):
     _fields_ = [
         ("lanes_per_chain", C.c_int32), ("chains_per_wave", C.c_int32), ("block_threads", C.c_int32),
         ("vgprs", C.c_int32), ("sgprs", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32),
-        ("max_blocks_per_cu", C.c_int32), ("num_cus", C.c_int32),
+        ("max_blocks_per_cu", C.c_int32), ("num_cus", C.c_int32), ("likelihood_form", C.c_int32),
         ("kernel_name", C.c_char * 128), ("device_name", C.c_char * 128),
     ]
 
@@ -63,6 +63,7 @@ class sepaihrd_mh_config(C.Structure):
 
 MH_COV_RUNNING, MH_COV_TWO_PASS = 0, 1
 FORM_AUTO, FORM_LANE_PER_AGE, FORM_QUAD = 0, 1, 2
+LL_INLINE, LL_SEPARATE_PASS, LL_CONSUMER_WAVES = 0, 1, 2
 
 
 def mh_create(lib, ctx, chains: int, iterations: int, x0: np.ndarray, cov0: np.ndarray, reg_eps: float = 1e-6,
