@@ -47,6 +47,7 @@
 #ifndef SEPAIHRD_HIP_H
 #define SEPAIHRD_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -397,6 +398,30 @@ int sepaihrd_mh_busy(sepaihrd_mh *mh);
 /* the constrained proposals of the last propose call, [C][P] (callers that track the best state) */
 int sepaihrd_mh_read_proposal(sepaihrd_mh *mh, double *prop);
 int sepaihrd_mh_history_length(const sepaihrd_mh *mh);
+
+/* ---- per-chain summary records across devices (the one exchange of the path) ----
+ *
+ * After sampling, the post-calibration summary needs the records of ALL chains -- [P posterior means | P variances |
+ * best value | accepted proposals] per chain, what sepaihrd_mh_summary_records writes -- the way the reference forms
+ * its ensemble statistics serially in ResultAggregator::aggregateBatchMetrics / aggregateAllBatches
+ * (src/model/ResultAggregator.cpp:35-172).  One process drives several devices (one context per device, one host
+ * thread each: MultiChainMetropolisHastings::optimizeChainGroupsOnDevice), so the collective is RCCL's single-process
+ * form: ncclCommInitAll over the contexts' devices, one ncclAllGather per device in a group call, over xGMI.
+ *   records_buffer   a device buffer owned by the context (grown on demand, freed with it): which = 0 the table of the chains
+ *                    this context ran (pass it to sepaihrd_mh_summary_records as d_out), which = 1 the gathered table
+ *   allgather_records  rows[k] records of `width` doubles from every context's buffer 0 into EVERY context's buffer 1, in
+ *                    context order.  backend AUTO: RCCL when librccl can be loaded (dlopen at first use: no link-time
+ *                    dependency) and no two contexts share a device, else staging through the host; RCCL / HOST force one
+ *                    (RCCL with two contexts on one device: SEPAIHRD_E_UNSUPPORTED).  *backend_used says which ran.
+ *   read_records / write_records   a context's buffer to / from the host (write grows it) */
+#define SEPAIHRD_GATHER_AUTO 0
+#define SEPAIHRD_GATHER_RCCL 1
+#define SEPAIHRD_GATHER_HOST 2
+double *sepaihrd_records_buffer(sepaihrd_ctx *ctx, int which, size_t doubles);
+int sepaihrd_allgather_records(sepaihrd_ctx *const *ctxs, int n, const int32_t *rows, int width, int backend,
+                               int *backend_used);
+int sepaihrd_read_records(sepaihrd_ctx *ctx, int which, double *out, size_t doubles);
+int sepaihrd_write_records(sepaihrd_ctx *ctx, int which, const double *in, size_t doubles);
 
 /* applyConstraints for B vectors on the host (exactly the device's arithmetic). */
 int sepaihrd_apply_constraints(const sepaihrd_ctx *ctx, int mode, const double *in, int B, double *out);

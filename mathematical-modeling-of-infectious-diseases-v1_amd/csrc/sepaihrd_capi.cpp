@@ -5,6 +5,7 @@
 #include "sepaihrd_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -74,6 +75,9 @@ struct sepaihrd_ctx {
     long timing_seen = 0;
     std::vector<hipEvent_t> ev;  // triples: before integrator, after integrator, after likelihood pass
     size_t ev_used = 0;
+    // per-chain summary records: the table of the chains this context ran, and the gathered table of all
+    double* rec_buf[2] = {nullptr, nullptr};
+    size_t rec_cap[2] = {0, 0};
 };
 
 namespace {
@@ -480,6 +484,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
 
 void sepaihrd_destroy(sepaihrd_ctx* ctx) {
     if (!ctx) return;
+    for (double* b : ctx->rec_buf) if (b) { (void)hipSetDevice(ctx->device); (void)hipFree(b); }
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     free_staging(ctx);
@@ -1515,6 +1520,176 @@ int sepaihrd_mh_read_covariance(sepaihrd_mh* mh, double* cov) {
     HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpy(cov, mh->st.cov, (size_t)mh->st.C * mh->st.P * mh->st.P * sizeof(double), hipMemcpyDeviceToHost), ctx,
             return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+// ------------------------------------------------------------------ summary records across devices
+// The one exchange of the path: after sampling, every device gets the fixed-width per-chain records of ALL chains so that
+// it can form the ensemble quantiles the reference computes serially (ResultAggregator.cpp:35-172).  One process drives
+// several devices here (one context / host thread per device, as optimizeChainGroupsOnDevice runs them), so the
+// collective is RCCL's single-process form: ncclCommInitAll over the contexts' devices and one ncclAllGather per device
+// inside a group call -- xGMI is point to point, each device's block goes to its peers directly.  RCCL is loaded at first
+// use (dlopen of librccl.so.1: the library has no link-time dependency on it, and a process that already carries a copy
+// -- PyTorch's -- shares it); without it, or when two contexts share a device (RCCL wants one rank per device), the
+// records are staged through the host.
+double* sepaihrd_records_buffer(sepaihrd_ctx* ctx, int which, size_t doubles) {
+    if (!ctx || which < 0 || which > 1) return nullptr;
+    if (doubles > ctx->rec_cap[which]) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+        if (ctx->rec_buf[which]) (void)hipFree(ctx->rec_buf[which]);
+        ctx->rec_buf[which] = nullptr;
+        ctx->rec_cap[which] = 0;
+        if (hipMalloc((void**)&ctx->rec_buf[which], doubles * sizeof(double)) != hipSuccess) {
+            ctx->last_error = "records_buffer: device allocation failed";
+            return nullptr;
+        }
+        ctx->rec_cap[which] = doubles;
+    }
+    return ctx->rec_buf[which];
+}
+
+int sepaihrd_read_records(sepaihrd_ctx* ctx, int which, double* out, size_t doubles) {
+    if (!ctx || which < 0 || which > 1 || !out || doubles > ctx->rec_cap[which]) return SEPAIHRD_E_INVALID_ARG;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(out, ctx->rec_buf[which], doubles * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_write_records(sepaihrd_ctx* ctx, int which, const double* in, size_t doubles) {
+    if (!ctx || which < 0 || which > 1 || !in) return SEPAIHRD_E_INVALID_ARG;
+    if (!sepaihrd_records_buffer(ctx, which, doubles)) return SEPAIHRD_E_HIP;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(ctx->rec_buf[which], in, doubles * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+extern "C++" {
+namespace {
+// the six RCCL entry points the gather needs, resolved once
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.AllGather;
+        return a;
+    }();
+    return api;
+}
+constexpr int NCCL_DOUBLE = 8;  // ncclFloat64 (rccl.h: ncclDataType_t)
+}  // namespace
+}  // extern "C++"
+
+int sepaihrd_allgather_records(sepaihrd_ctx* const* ctxs, int n, const int32_t* rows, int width, int backend, int* backend_used) {
+    if (!ctxs || n <= 0 || !rows || width <= 0 || backend < SEPAIHRD_GATHER_AUTO || backend > SEPAIHRD_GATHER_HOST) return SEPAIHRD_E_INVALID_ARG;
+    for (int k = 0; k < n; ++k)
+        if (!ctxs[k] || rows[k] < 0) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* c0 = ctxs[0];
+    size_t total = 0;
+    int max_rows = 0;
+    for (int k = 0; k < n; ++k) { total += (size_t)rows[k]; max_rows = std::max(max_rows, (int)rows[k]); }
+    for (int k = 0; k < n; ++k)
+        if ((size_t)rows[k] * width > ctxs[k]->rec_cap[0]) { c0->last_error = "allgather_records: a context's local table (records_buffer 0) is smaller than rows * width"; return SEPAIHRD_E_INVALID_ARG; }
+    bool distinct = true;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) distinct = distinct && ctxs[a]->device != ctxs[b]->device;
+    const bool can_rccl = distinct && rccl_api().ok;
+    if (backend == SEPAIHRD_GATHER_RCCL && !can_rccl) {
+        c0->last_error = !distinct ? "allgather_records: RCCL wants one rank per device, two contexts share one" : "allgather_records: librccl could not be loaded";
+        return SEPAIHRD_E_UNSUPPORTED;
+    }
+    const bool use_rccl = backend == SEPAIHRD_GATHER_RCCL || (backend == SEPAIHRD_GATHER_AUTO && can_rccl);
+    if (backend_used) *backend_used = use_rccl ? SEPAIHRD_GATHER_RCCL : SEPAIHRD_GATHER_HOST;
+    for (int k = 0; k < n; ++k)
+        if (!sepaihrd_records_buffer(ctxs[k], 1, total * width)) { c0->last_error = "allgather_records: no room for the gathered table"; return SEPAIHRD_E_HIP; }
+
+    if (!use_rccl) {  // host staging: every local table down, the whole table up
+        std::vector<double> table(total * width);
+        size_t off = 0;
+        for (int k = 0; k < n; ++k) {
+            HIP_TRY(hipSetDevice(ctxs[k]->device), c0, return SEPAIHRD_E_HIP);
+            HIP_TRY(hipMemcpy(table.data() + off, ctxs[k]->rec_buf[0], (size_t)rows[k] * width * sizeof(double), hipMemcpyDeviceToHost), c0, return SEPAIHRD_E_HIP);
+            off += (size_t)rows[k] * width;
+        }
+        for (int k = 0; k < n; ++k) {
+            HIP_TRY(hipSetDevice(ctxs[k]->device), c0, return SEPAIHRD_E_HIP);
+            HIP_TRY(hipMemcpy(ctxs[k]->rec_buf[1], table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice), c0, return SEPAIHRD_E_HIP);
+        }
+        return SEPAIHRD_OK;
+    }
+
+    // RCCL: equal counts per rank, so every rank sends max_rows rows (its table padded) and the blocks are compacted after
+    const RcclApi& rc = rccl_api();
+    const size_t block = (size_t)max_rows * width;
+    std::vector<int> devs(n);
+    for (int k = 0; k < n; ++k) devs[k] = ctxs[k]->device;
+    std::vector<void*> comms(n, nullptr);
+    std::vector<double*> send(n, nullptr), recv(n, nullptr);
+    std::vector<hipStream_t> streams(n, nullptr);
+    int rc_code = 0;
+    auto fail = [&](const char* what) {
+        c0->last_error = std::string("allgather_records: ") + what + (rc_code && rc.GetErrorString ? std::string(": ") + rc.GetErrorString(rc_code) : std::string());
+        for (int k = 0; k < n; ++k) {
+            (void)hipSetDevice(devs[k]);
+            if (send[k]) (void)hipFree(send[k]);
+            if (recv[k]) (void)hipFree(recv[k]);
+            if (streams[k]) (void)hipStreamDestroy(streams[k]);
+            if (comms[k]) (void)rc.CommDestroy(comms[k]);
+        }
+        return SEPAIHRD_E_HIP;
+    };
+    for (int k = 0; k < n; ++k) {
+        if (hipSetDevice(devs[k]) != hipSuccess || hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void**)&send[k], block * sizeof(double)) != hipSuccess || hipMalloc((void**)&recv[k], block * n * sizeof(double)) != hipSuccess ||
+            hipMemsetAsync(send[k], 0, block * sizeof(double), streams[k]) != hipSuccess ||
+            hipMemcpyAsync(send[k], ctxs[k]->rec_buf[0], (size_t)rows[k] * width * sizeof(double), hipMemcpyDeviceToDevice, streams[k]) != hipSuccess)
+            return fail("staging buffers");
+    }
+    if ((rc_code = rc.CommInitAll(comms.data(), n, devs.data())) != 0) return fail("ncclCommInitAll");
+    if ((rc_code = rc.GroupStart()) != 0) return fail("ncclGroupStart");
+    for (int k = 0; k < n; ++k) {
+        (void)hipSetDevice(devs[k]);
+        if ((rc_code = rc.AllGather(send[k], recv[k], block, NCCL_DOUBLE, comms[k], streams[k])) != 0) { (void)rc.GroupEnd(); return fail("ncclAllGather"); }
+    }
+    if ((rc_code = rc.GroupEnd()) != 0) return fail("ncclGroupEnd");
+    rc_code = 0;
+    for (int k = 0; k < n; ++k) {  // compact: rank r's first rows[r] rows, in rank order
+        (void)hipSetDevice(devs[k]);
+        size_t off = 0;
+        for (int r = 0; r < n; ++r) {
+            if (rows[r] > 0 && hipMemcpyAsync(ctxs[k]->rec_buf[1] + off, recv[k] + (size_t)r * block, (size_t)rows[r] * width * sizeof(double),
+                                              hipMemcpyDeviceToDevice, streams[k]) != hipSuccess)
+                return fail("compaction");
+            off += (size_t)rows[r] * width;
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        (void)hipSetDevice(devs[k]);
+        if (hipStreamSynchronize(streams[k]) != hipSuccess) return fail("stream synchronisation");
+    }
+    for (int k = 0; k < n; ++k) {
+        (void)hipSetDevice(devs[k]);
+        (void)hipFree(send[k]); (void)hipFree(recv[k]); (void)hipStreamDestroy(streams[k]); (void)rc.CommDestroy(comms[k]);
+    }
     return SEPAIHRD_OK;
 }
 

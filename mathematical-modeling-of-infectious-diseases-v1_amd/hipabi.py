@@ -64,6 +64,7 @@ class sepaihrd_mh_config(C.Structure):
 MH_COV_RUNNING, MH_COV_TWO_PASS = 0, 1
 FORM_AUTO, FORM_LANE_PER_AGE, FORM_QUAD = 0, 1, 2
 LL_INLINE, LL_SEPARATE_PASS, LL_CONSUMER_WAVES = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_HOST = 0, 1, 2
 
 
 def mh_create(lib, ctx, chains: int, iterations: int, x0: np.ndarray, cov0: np.ndarray, reg_eps: float = 1e-6,
@@ -88,6 +89,7 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_mh_step_tested", "sepaihrd_mh_fetch_test", "sepaihrd_mh_commit", "sepaihrd_mh_adapt", "sepaihrd_mh_read_history",
     "sepaihrd_mh_read_covariance", "sepaihrd_mh_read_proposal", "sepaihrd_mh_history_length",
     "sepaihrd_mh_sample_count", "sepaihrd_mh_read_samples", "sepaihrd_mh_read_moments", "sepaihrd_mh_summary_records",
+    "sepaihrd_records_buffer", "sepaihrd_allgather_records", "sepaihrd_read_records", "sepaihrd_write_records",
 )
 
 _lib = None
@@ -140,6 +142,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_mh_read_samples.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.sepaihrd_mh_read_moments.argtypes = [vp, vp, vp]
     lib.sepaihrd_mh_summary_records.argtypes = [vp, C.c_int, vp, vp]
+    lib.sepaihrd_records_buffer.restype = vp
+    lib.sepaihrd_records_buffer.argtypes = [vp, C.c_int, C.c_size_t]
+    lib.sepaihrd_allgather_records.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.sepaihrd_read_records.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.sepaihrd_write_records.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.sepaihrd_mh_destroy.restype = None
     lib.sepaihrd_mh_destroy.argtypes = [vp]
     lib.sepaihrd_mh_evaluate_current.argtypes = [vp, vp, vp]

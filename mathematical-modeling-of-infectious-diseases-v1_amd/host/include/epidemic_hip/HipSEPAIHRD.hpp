@@ -249,6 +249,20 @@ public:
     std::vector<OptimizationResult> optimizeChainGroupsOnDevice(const std::vector<double>& initial, int C,
                                                                 const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives,
                                                                 IParameterManager& parameterManager);
+    // Per-chain summary records of the last device-resident run, chain-major [C][2 P + 2]: posterior means and variances
+    // over the stored samples after burn-in, the chain's best value, its accepted proposals (formed on the
+    // device, sepaihrd_mh_summary_records).  They also stay on each objective's device (sepaihrd_records_buffer 0).
+    const std::vector<double>& chainSummaries() const { return summary_records_; }
+    // The one exchange of the path: after optimizeChainGroupsOnDevice, every group's device receives the records of ALL
+    // chains (RCCL ncclAllGather over the groups' devices when they are distinct and librccl loads, staging through the host
+    // otherwise), so that the ensemble statistics the reference forms serially (ResultAggregator.cpp:35-172) can be
+    // formed next to the data on any device.  backend: SEPAIHRD_GATHER_AUTO / _RCCL / _HOST; returns the one used.
+    int gatherChainSummaries(const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives, int backend = 0);
+    // the gathered table as one group's device holds it (after gatherChainSummaries)
+    std::vector<double> gatheredSummaries(HipSEPAIHRDObjectiveFunction& objective) const;
+    // exact-sort quantiles across chains of every record column, probs x width (the rule of the reference's trajectory
+    // quantiles, PostCalibrationAnalyser.cpp:303-340: v[floor(pos)] (1 - f) + v[floor(pos) + 1] f, pos = q (n - 1))
+    static std::vector<double> summaryQuantiles(const std::vector<double>& table, int width, const std::vector<double>& probs);
     void setHostThreads(int n) { host_threads_ = n; }  // per-run cap on the OpenMP team (0 = the CPU share)
     // recomputeFullCovariance (MetropolisHastingsSampler.cpp:168-199) as the reference writes it -- two passes over the
     // whole chain history, O(t P^2) per refresh and every state kept -- instead of the running co-moments the sampler
@@ -273,6 +287,9 @@ private:
     bool two_pass_covariance_ = false;
     int adaptation_window_ = 0;  // ring of newest states on the device (0: adaptation period + 1, at least 128)
     double last_loop_seconds_ = 0.0;
+    std::vector<double> summary_records_;  // [C][2 P + 2] of the last device-resident run
+    std::vector<int> group_rows_;          // chains per group of the last grouped run
+    int summary_width_ = 0;
 };
 
 }  // namespace epidemic

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -659,6 +660,19 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 
     std::vector<double> rows, covs(static_cast<size_t>(C) * PP);
     const int ns = store_samples_ ? sepaihrd_mh_sample_count(mh) : 0;  // state 0 and every thinning-th one (:266-268,357-360)
+    summary_records_.clear();
+    summary_width_ = 2 * P + 2;
+    group_rows_.assign(1, C);
+    if (ns > 0 && iterations_ > 1) {
+        // per-chain summary over the samples after burn-in (all of them when none is): formed on the device, left in the
+        // context's records buffer for a later all-gather, copied here
+        int first = burn_in_ / thinning_ + 1;
+        if (first >= ns) first = 0;
+        double* d_rec = sepaihrd_records_buffer(ctx, 0, static_cast<size_t>(C) * summary_width_);
+        if (!d_rec) throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_records_buffer: ") + sepaihrd_last_error(ctx));
+        summary_records_.resize(static_cast<size_t>(C) * summary_width_);
+        check(sepaihrd_mh_summary_records(mh, first, summary_records_.data(), d_rec), "mh_summary_records");
+    }
     if (ns > 0) {
         rows.resize(static_cast<size_t>(C) * ns * P);
         check(sepaihrd_mh_read_samples(mh, 0, ns, rows.data()), "mh_read_samples");
@@ -724,6 +738,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
     std::vector<std::vector<std::vector<unsigned char>>> part_traces(static_cast<size_t>(G));
     std::vector<std::string> errors(static_cast<size_t>(G));
     std::vector<double> loop_secs(static_cast<size_t>(G), 0.0);
+    std::vector<std::vector<double>> part_records(static_cast<size_t>(G));
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g) {
         workers.emplace_back([&, g]() {
@@ -735,6 +750,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
                 const std::vector<double> init(initial.begin() + static_cast<size_t>(c0) * P, initial.begin() + static_cast<size_t>(c1) * P);
                 parts[static_cast<size_t>(g)] = local.optimizeChainsOnDevice(init, c1 - c0, *objectives[static_cast<size_t>(g)], pm);
                 part_traces[static_cast<size_t>(g)] = local.traces_;
+                part_records[static_cast<size_t>(g)] = local.summary_records_;
                 loop_secs[static_cast<size_t>(g)] = local.last_loop_seconds_;
             } catch (const std::exception& e) { errors[static_cast<size_t>(g)] = e.what(); }
         });
@@ -745,11 +761,60 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
     std::vector<OptimizationResult> results;
     traces_.clear();
     last_loop_seconds_ = *std::max_element(loop_secs.begin(), loop_secs.end());
+    summary_records_.clear();
+    summary_width_ = 2 * P + 2;
+    group_rows_.clear();
     for (int g = 0; g < G; ++g) {
         for (OptimizationResult& r : parts[static_cast<size_t>(g)]) results.push_back(std::move(r));
         for (auto& t : part_traces[static_cast<size_t>(g)]) traces_.push_back(std::move(t));
+        summary_records_.insert(summary_records_.end(), part_records[static_cast<size_t>(g)].begin(), part_records[static_cast<size_t>(g)].end());
+        group_rows_.push_back(first[static_cast<size_t>(g) + 1] - first[static_cast<size_t>(g)]);
     }
     return results;
+}
+
+int MultiChainMetropolisHastings::gatherChainSummaries(const std::vector<HipSEPAIHRDObjectiveFunction*>& objectives, int backend) {
+    const int G = static_cast<int>(objectives.size());
+    if (G <= 0 || static_cast<size_t>(G) != group_rows_.size() || summary_records_.empty())
+        throw InvalidParameterException("MetropolisHastingsSampler", "gatherChainSummaries: run optimizeChainGroupsOnDevice over these objectives first (with stored samples)");
+    std::vector<sepaihrd_ctx*> ctxs;
+    std::vector<int32_t> rows;
+    for (int g = 0; g < G; ++g) {
+        ctxs.push_back(objectives[static_cast<size_t>(g)]->deviceContext());
+        rows.push_back(group_rows_[static_cast<size_t>(g)]);
+    }
+    int used = 0;
+    if (sepaihrd_allgather_records(ctxs.data(), G, rows.data(), summary_width_, backend, &used) != SEPAIHRD_OK)
+        throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_allgather_records: ") + sepaihrd_last_error(ctxs[0]));
+    return used;
+}
+
+std::vector<double> MultiChainMetropolisHastings::gatheredSummaries(HipSEPAIHRDObjectiveFunction& objective) const {
+    std::vector<double> out(summary_records_.size());
+    if (sepaihrd_read_records(objective.deviceContext(), 1, out.data(), out.size()) != SEPAIHRD_OK)
+        throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_read_records: ") + sepaihrd_last_error(objective.deviceContext()));
+    return out;
+}
+
+std::vector<double> MultiChainMetropolisHastings::summaryQuantiles(const std::vector<double>& table, int width, const std::vector<double>& probs) {
+    if (width <= 0 || table.size() % static_cast<size_t>(width) != 0)
+        throw InvalidParameterException("MetropolisHastingsSampler", "summaryQuantiles: table size is not a multiple of the record width");
+    const size_t n = table.size() / static_cast<size_t>(width);
+    std::vector<double> out(probs.size() * static_cast<size_t>(width), std::numeric_limits<double>::quiet_NaN());
+    if (n == 0) return out;
+    std::vector<double> col(n);
+    for (int w = 0; w < width; ++w) {
+        for (size_t c = 0; c < n; ++c) col[c] = table[c * width + w];
+        std::sort(col.begin(), col.end());
+        for (size_t q = 0; q < probs.size(); ++q) {
+            const double pos = probs[q] * static_cast<double>(n - 1);
+            const size_t lo = static_cast<size_t>(std::floor(pos));
+            const size_t hi = std::min(lo + 1, n - 1);
+            const double f = pos - static_cast<double>(lo);
+            out[q * width + w] = col[lo] * (1.0 - f) + col[hi] * f;
+        }
+    }
+    return out;
 }
 
 }  // namespace epidemic

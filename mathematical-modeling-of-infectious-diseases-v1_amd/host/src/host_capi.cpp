@@ -525,6 +525,61 @@ int host_nuts_run(void* hv, const sepaihrd_problem* pb, int device, int iteratio
     }
 }
 
+// Pure host (no GPU): exact-sort quantiles across chains of every column of a summary table, out [n_probs][width].
+int host_summary_quantiles(const double* table, int rows, int width, const double* probs, int n_probs, double* out) {
+    try {
+        const std::vector<double> q = MultiChainMetropolisHastings::summaryQuantiles(
+            std::vector<double>(table, table + static_cast<size_t>(rows) * width), width, std::vector<double>(probs, probs + n_probs));
+        std::copy(q.begin(), q.end(), out);
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// optimizeChainGroupsOnDevice with stored samples, then the all-gather of the per-chain summary records over the
+// groups' devices.  records [C][2P+2] (host concatenation, chain order), gathered [G][C][2P+2] (what each group's device
+// holds afterwards), samples [C][n_samples][P], best_value [C], accepted [C]; *backend_used: SEPAIHRD_GATHER_RCCL / _HOST.
+int host_mh_groups_summaries(void** handles, int G, int C, const double* initial, uint32_t seed, int iterations, int burn_in,
+                             int adaptation_period, int thinning, int backend, double* records, double* gathered, double* samples,
+                             double* best_value, int32_t* accepted, int32_t* backend_used) {
+    try {
+        auto* h0 = static_cast<HostHandle*>(handles[0]);
+        const int P = static_cast<int>(h0->pm->getParameterCount());
+        std::vector<HipSEPAIHRDObjectiveFunction*> objs;
+        for (int g = 0; g < G; ++g) objs.push_back(static_cast<HostHandle*>(handles[g])->obj.get());
+        MultiChainMetropolisHastings mh;
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+                      {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)}, {"store_samples", 1.0}});
+        mh.setSeed(seed);
+        const std::vector<OptimizationResult> res =
+            mh.optimizeChainGroupsOnDevice(std::vector<double>(initial, initial + static_cast<size_t>(C) * P), C, objs, *h0->pm);
+        const std::vector<double>& rec = mh.chainSummaries();
+        if (records) std::copy(rec.begin(), rec.end(), records);
+        const int used = mh.gatherChainSummaries(objs, backend);
+        if (backend_used) *backend_used = used;
+        if (gathered)
+            for (int g = 0; g < G; ++g) {
+                const std::vector<double> t = mh.gatheredSummaries(*objs[static_cast<size_t>(g)]);
+                std::copy(t.begin(), t.end(), gathered + static_cast<size_t>(g) * rec.size());
+            }
+        const size_t ns = res[0].samples.size();
+        for (int c = 0; c < C; ++c) {
+            const OptimizationResult& r = res[static_cast<size_t>(c)];
+            if (best_value) best_value[c] = r.bestObjectiveValue;
+            if (accepted) accepted[c] = static_cast<int32_t>(r.additionalStats.at("accepted_count"));
+            if (samples)
+                for (size_t k = 0; k < ns; ++k)
+                    for (int i = 0; i < P; ++i) samples[(static_cast<size_t>(c) * ns + k) * P + i] = r.samples[k][i];
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
 // optimizeChainGroupsOnDevice over G handles (one device context each; parameter manager of the first).
 // Outputs as host_mh_run, without the samples.
 int host_mh_run_groups(void** handles, int G, int C, const double* initial, uint32_t seed, int iterations, int burn_in,

@@ -347,3 +347,40 @@ def model_holders(ends_after, values_after, baseline, baseline_end, t) -> dict:
     if rc:
         raise RuntimeError("host_model_holders: rc %d %s" % (rc, lib.host_last_error().decode()))
     return {"kappa": kap, "schedule_ends": se, "schedule_values": sv, "state_size": size.value, "names": buf.value.decode()}
+
+
+def summary_quantiles(table, probs) -> np.ndarray:
+    """MultiChainMetropolisHastings::summaryQuantiles (pure host): exact-sort quantiles across chains of every column."""
+    lib = load_library()
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    q = np.ascontiguousarray(probs, dtype=np.float64)
+    out = np.empty((len(q), t.shape[1]))
+    lib.host_summary_quantiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    if lib.host_summary_quantiles(t.ctypes.data, t.shape[0], t.shape[1], q.ctypes.data, len(q), out.ctypes.data):
+        raise RuntimeError(lib.host_last_error().decode())
+    return out
+
+
+def metropolis_hastings_group_summaries(objectives, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
+                                        thinning: int = 1, backend: int = 0) -> dict:
+    """optimizeChainGroupsOnDevice + gatherChainSummaries: the per-chain summary records (host concatenation), the table
+    every group's device holds after the all-gather, and the samples they were formed from."""
+    lib = load_library()
+    x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
+    Cn, P = x0.shape
+    G = len(objectives)
+    W = 2 * P + 2
+    n_s = 1 + (max(iterations, 1) - 1) // max(1, thinning)
+    handles = (C.c_void_p * G)(*[o.h for o in objectives])
+    records, gathered = np.zeros((Cn, W)), np.zeros((G, Cn, W))
+    samples, best_value, accepted = np.zeros((Cn, n_s, P)), np.zeros(Cn), np.zeros(Cn, dtype=np.int32)
+    used = C.c_int32(-1)
+    lib.host_mh_groups_summaries.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.host_mh_groups_summaries(handles, G, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning, backend,
+                                      records.ctypes.data, gathered.ctypes.data, samples.ctypes.data, best_value.ctypes.data,
+                                      accepted.ctypes.data, C.byref(used))
+    if rc:
+        raise RuntimeError(lib.host_last_error().decode())
+    return {"records": records, "gathered": gathered, "samples": samples, "best_value": best_value, "accepted": accepted,
+            "backend_used": int(used.value)}

@@ -526,6 +526,81 @@ def test_headline_batch_accept_traces_in_production_arithmetic(mm, oracle_py, sy
     assert 0.02 < dev["accept_trace"].mean() < 0.9
 
 
+def test_chain_summaries_gathered_over_two_groups_on_one_device(mm, shipped):
+    """SURVEY 8(e) from the C++ host: optimizeChainGroupsOnDevice over two objectives, the per-chain summary records formed
+    on the device ([P means | P variances | best value | accepted proposals] over the samples after burn-in) equal numpy
+    on the returned samples, and gatherChainSummaries leaves the table of ALL chains on both groups' devices.  Two
+    contexts on ONE device: the gather stages through the host (RCCL wants one rank per device) and says so; forcing
+    RCCL is refused."""
+    from mmid_amd import draws, hipabi
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    C, P = 11, pb.n_params
+    x0 = draws.jitter_draws(pb, 7, C)
+    objs = [mm.HostObjective(pb), mm.HostObjective(pb)]
+    kw = dict(seed=5, iterations=121, burn_in=40, adaptation_period=30, thinning=10)
+    out = mm.hostabi.metropolis_hastings_group_summaries(objs, x0, **kw)
+    assert out["backend_used"] == hipabi.GATHER_HOST
+    kept = out["samples"][:, 5:]                      # samples of iterations 50, 60, ... 120: after the burn-in of 40
+    rec = out["records"]
+    np.testing.assert_allclose(rec[:, :P], kept.mean(axis=1), rtol=1e-13)
+    np.testing.assert_allclose(rec[:, P:2 * P], kept.var(axis=1, ddof=1), rtol=1e-9, atol=1e-30)
+    assert np.array_equal(rec[:, 2 * P], out["best_value"]) and np.array_equal(rec[:, 2 * P + 1], out["accepted"])
+    assert np.array_equal(out["gathered"][0], rec) and np.array_equal(out["gathered"][1], rec)
+    one = mm.HostObjective(pb).metropolis_hastings(x0, device_state=True, **kw)     # same chains in one group
+    assert np.array_equal(one["samples"], out["samples"])
+    with pytest.raises(RuntimeError, match="one rank per device"):
+        mm.hostabi.metropolis_hastings_group_summaries(objs, x0, backend=hipabi.GATHER_RCCL, **kw)
+
+
+def test_rccl_allgather_entry_point_single_rank(mm, shipped):
+    """The RCCL form of the exchange executed on the one device a box has: ncclCommInitAll over one device, ncclAllGather
+    inside a group call, compaction -- a single rank, so the gathered table is the local one.  (More than one rank needs
+    more than one device: test_rccl_allgather_over_two_devices below, skipped on one-GPU boxes.)"""
+    import ctypes as C
+    from mmid_amd import hipabi
+    lib = hipabi.load_library()
+    hip = mm.HipObjective(shipped)
+    rows, width = 37, 2 * shipped.n_params + 2
+    table = np.random.RandomState(1).normal(size=(rows, width))
+    assert lib.sepaihrd_write_records(hip.ctx, 0, table.ctypes.data, table.size) == 0
+    assert lib.sepaihrd_records_buffer(hip.ctx, 0, table.size)
+    ctxs = (C.c_void_p * 1)(hip.ctx)
+    nrows = np.array([rows], dtype=np.int32)
+    used = C.c_int(-1)
+    rc = lib.sepaihrd_allgather_records(ctxs, 1, nrows.ctypes.data, width, hipabi.GATHER_RCCL, C.byref(used))
+    assert rc == 0, lib.sepaihrd_last_error(hip.ctx)
+    assert used.value == hipabi.GATHER_RCCL
+    back = np.empty_like(table)
+    assert lib.sepaihrd_read_records(hip.ctx, 1, back.ctypes.data, back.size) == 0
+    assert np.array_equal(back, table)
+
+
+def test_rccl_allgather_over_two_devices(mm, shipped):
+    """One context per device, ragged shares (5 + 3 rows): every device ends up with all 8 records in device order,
+    through RCCL."""
+    import ctypes as C
+    import torch
+    from mmid_amd import hipabi
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    lib = hipabi.load_library()
+    hips = [mm.HipObjective(shipped, device=0), mm.HipObjective(shipped, device=1)]
+    width = 2 * shipped.n_params + 2
+    parts = [np.random.RandomState(k).normal(size=(r, width)) for k, r in enumerate((5, 3))]
+    for h, t in zip(hips, parts):
+        assert lib.sepaihrd_write_records(h.ctx, 0, t.ctypes.data, t.size) == 0
+    ctxs = (C.c_void_p * 2)(*[h.ctx for h in hips])
+    nrows = np.array([5, 3], dtype=np.int32)
+    used = C.c_int(-1)
+    assert lib.sepaihrd_allgather_records(ctxs, 2, nrows.ctypes.data, width, hipabi.GATHER_AUTO, C.byref(used)) == 0
+    assert used.value == hipabi.GATHER_RCCL
+    want = np.concatenate(parts)
+    for h in hips:
+        back = np.empty_like(want)
+        assert lib.sepaihrd_read_records(h.ctx, 1, back.ctypes.data, back.size) == 0
+        assert np.array_equal(back, want)
+
+
 def test_reference_constructor_argument_lists(mm, shipped):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,

@@ -443,3 +443,19 @@ def test_adapter_maps_every_failure_status_to_the_references_exception(mm):
         seen.add(msg)
         if status >= 3:
             assert name in msg
+
+
+def test_summary_quantiles_of_gathered_chain_records(mm):
+    """The host side of the post-calibration exchange needs no GPU: per-chain summary records of two groups
+    of chains concatenated in chain order, then exact-sort quantiles across chains of every column -- the rule of the
+    reference's trajectory quantiles (PostCalibrationAnalyser.cpp:303-340), numpy's linear-interpolation quantile."""
+    rs = np.random.RandomState(3)
+    group_a, group_b = rs.normal(size=(6, 10)), rs.normal(size=(5, 10))
+    table = np.concatenate([group_a, group_b])
+    probs = [0.025, 0.5, 0.975, 0.0, 1.0]
+    got = mm.hostabi.summary_quantiles(table, probs)
+    np.testing.assert_allclose(got, np.quantile(table, probs, axis=0), rtol=1e-13, atol=1e-15)
+    assert np.array_equal(mm.hostabi.summary_quantiles(table[:1], [0.3]), table[:1])   # one chain: its own value
+    # the Python mirror used on the torch.distributed path gives the same numbers
+    import torch
+    np.testing.assert_allclose(mm.parallel.ensemble_quantiles(torch.from_numpy(table), probs[:3]).numpy(), got[:3], rtol=1e-13)
