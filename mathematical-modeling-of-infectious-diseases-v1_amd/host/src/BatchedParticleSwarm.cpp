@@ -47,15 +47,16 @@ void BatchedParticleSwarmOptimization::configure(const std::map<std::string, dou
         {"restart_threshold", ANY, as_double(restart_threshold_)},
         {"quantum_beta", ANY, as_double(quantum_beta_)},
         {"levy_alpha", ANY, as_double(levy_alpha_)},
-        {"seed", ANY, [this](double v) { seed_ = static_cast<uint32_t>(v); }},  // build-side: replaces std::random_device (:578)
+        {"seed", NON_NEGATIVE, [this](double v) { seed_ = static_cast<uint32_t>(std::fmod(v, 4294967296.0)); }},  // build-side: replaces std::random_device (:578)
     };
     for (const Setting& row : table) {
         const auto it = settings.find(row.key);
         if (it == settings.end()) continue;
         const double v = it->second;
-        const int whole = static_cast<int>(v);
+        // the enum ranges are checked on the double itself: a float-to-int conversion of a value the int cannot hold
+        // (a seed of 3e9 in an ANY row) is undefined behaviour
         const bool ok = row.range == ANY || (row.range == POSITIVE && v > 0) || (row.range == NON_NEGATIVE && v >= 0) ||
-                        (row.range == ENUM_0_4 && whole >= 0 && whole <= 4) || (row.range == ENUM_0_3 && whole >= 0 && whole <= 3);
+                        (row.range == ENUM_0_4 && v >= 0.0 && v < 5.0) || (row.range == ENUM_0_3 && v >= 0.0 && v < 4.0);
         if (!ok) {
             static const char* what[] = {"", "a positive number", "zero or a positive number", "one of 0..4", "one of 0..3"};
             throw std::invalid_argument(std::string("particle swarm setting '") + row.key + "' = " + std::to_string(v) +
