@@ -379,6 +379,19 @@ int sepaihrd_mh_step(sepaihrd_mh *mh, const uint8_t *accept, const double *scale
  *                  bookkeeping for iteration t then runs while evaluation t + 1 does.  One test in flight at a time.
  *   set_values     the chains' current values before the first test (the values of x0). */
 int sepaihrd_mh_set_values(sepaihrd_mh *mh, const double *values);
+/* The chains' random streams ON THE DEVICE.  The reference draws from one std::mt19937 per chain: the normals of a proposal
+ * (std::normal_distribution: polar method over generate_canonical<double, 53>, sqrt(-2 log(r2) / r2)) and, only when
+ * log_ratio < 0, one uniform whose std::log the accept test compares (MetropolisHastingsSampler.cpp:93-97,327).  Drawn on the
+ * host these set the pace at BASELINE chain counts (16 host threads: ~6.7 M proposals/s whatever the batch).  Every step of
+ * that recipe is integer arithmetic or a correctly rounded IEEE operation except std::log, and glibc's log is written out
+ * for the device (csrc/sepaihrd_rng.inc: bit-identical to the libm of this image on a CPU with FMA), so the device draws
+ * the SAME values from the SAME stream positions:
+ *   seed_streams  chain c gets std::mt19937(seed0 + c); from then on step_tested draws log(u) and the normals of both
+ *                 continuations itself (the caller fills only the two scale candidates of the test buffer) and the stream
+ *                 moves by what the continuation taken used;
+ *   draw_first    the normals of proposal 1 from the start of every stream, staged for sepaihrd_mh_step. */
+int sepaihrd_mh_seed_streams(sepaihrd_mh *mh, uint32_t seed0);
+int sepaihrd_mh_draw_first(sepaihrd_mh *mh);
 double *sepaihrd_mh_test_buffer(sepaihrd_mh *mh);
 int sepaihrd_mh_step_tested(sepaihrd_mh *mh, double gamma, int adapt, int last);
 int sepaihrd_mh_fetch_test(sepaihrd_mh *mh, double *values, uint8_t *flags);

@@ -938,6 +938,7 @@ struct sepaihrd_mh {
     bool r1_in_flight = false;
     // states [mom_rows, rows) have not entered the running sums yet (see mh_moments_catchup_kernel)
     int mom_rows = 0;
+    bool device_rng = false;  // the chains' mt19937 streams live on the device (sepaihrd_mh_seed_streams)
     int covariance_mode = SEPAIHRD_MH_COV_RUNNING;
     int iterations = 0;
     double* d_summary = nullptr;
@@ -1100,6 +1101,9 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     dalloc((void**)&st.wmean, CP * sizeof(double));
     dalloc((void**)&st.m2, CPP * sizeof(double));
     dalloc((void**)&st.accepted, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&st.mt, (size_t)C * 624 * sizeof(uint32_t));
+    dalloc((void**)&st.mt_idx, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&st.mt_used, (size_t)C * 2 * sizeof(int32_t));
     dalloc((void**)&mh->d_summary, (size_t)C * (2 * (size_t)P + 2) * sizeof(double));
     dalloc((void**)&mh->d_z, CP * sizeof(double));
     dalloc((void**)&mh->d_scale, (size_t)C * sizeof(double));
@@ -1132,6 +1136,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     if (ok && hipEventCreateWithFlags(&mh->ev_staged, hipEventDisableTiming) != hipSuccess) ok = false;
     for (hipEvent_t* e : {&mh->ev_test_up, &mh->ev_tested, &mh->ev_fetched, &mh->ev_proposed, &mh->ev_r1})
         if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) ok = false;
+    if (ok) ok = hipMemsetAsync(mh->d_test_out, 0, (size_t)C * (sizeof(double) + 1), mh->stream) == hipSuccess;
     if (ok) ok = hipMemsetAsync(st.sum, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
                  hipMemsetAsync(st.wmean, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
                  hipMemsetAsync(st.m2, 0, CPP * sizeof(double), mh->stream) == hipSuccess &&
@@ -1295,13 +1300,35 @@ int sepaihrd_mh_set_values(sepaihrd_mh* mh, const double* values) {
 
 double* sepaihrd_mh_test_buffer(sepaihrd_mh* mh) { return mh ? mh->h_test : nullptr; }
 
+int sepaihrd_mh_seed_streams(sepaihrd_mh* mh, uint32_t seed0) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (sampler_seed_streams(mh->st, seed0, mh->stream) != 0) { ctx->last_error = "mh_seed_streams: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    mh->device_rng = true;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_draw_first(sepaihrd_mh* mh) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (!mh->device_rng) { ctx->last_error = "mh_draw_first: call sepaihrd_mh_seed_streams first"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    // proposal 1: the normals from the start of every stream, into the staged-normals buffer
+    if (sampler_draw(mh->st, nullptr, 1, nullptr, mh->d_z_stage, nullptr, 1, mh->copy_stream) != 0) { ctx->last_error = "mh_draw_first: launch failed"; return SEPAIHRD_E_HIP; }
+    HIP_TRY(hipEventRecord(mh->ev_staged, mh->copy_stream), ctx, return SEPAIHRD_E_HIP);
+    mh->staged = true;
+    return SEPAIHRD_OK;
+}
+
 int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) {
     if (!mh || adapt < 0 || adapt > 3) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     const int C = mh->st.C, P = mh->st.P;
     if (!mh->values_set) { ctx->last_error = "mh_step_tested: call sepaihrd_mh_set_values first"; return SEPAIHRD_E_INVALID_ARG; }
     if (mh->test_pending) { ctx->last_error = "mh_step_tested: the previous test has not been fetched"; return SEPAIHRD_E_INVALID_ARG; }
-    if (!last && !mh->staged) { ctx->last_error = "mh_step_tested: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
+    if (!last && !mh->staged && !mh->device_rng) { ctx->last_error = "mh_step_tested: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
     if (mh->rows >= mh->iterations) { ctx->last_error = "mh_step_tested: more states than the sampler was created for"; return SEPAIHRD_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     hipStream_t st = mh->stream, cs = mh->copy_stream;
@@ -1309,6 +1336,19 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     // the test's inputs travel on the copy stream while the evaluation still runs; they may not overwrite what the
     // previous proposal is reading
     if (mh->proposed_once) HIP_TRY(hipStreamWaitEvent(cs, mh->ev_last_proposed, 0), ctx, return SEPAIHRD_E_HIP);
+    if (mh->device_rng) {
+        // the caller supplies the two scale candidates only; log(u) and the normals of both continuations are drawn here,
+        // from where the previous test left every chain's stream (its flags are final: the copy stream has just waited
+        // for the kernel that wrote them)
+        HIP_TRY(hipMemcpyAsync(mh->d_test + C, mh->h_test + C, 2 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
+                return SEPAIHRD_E_HIP);
+        uint8_t* const prev_flags = reinterpret_cast<uint8_t*>(static_cast<double*>(mh->d_test_out) + C);
+        if (sampler_draw(mh->st, prev_flags, 0, mh->d_test, mh->d_z_stage, mh->d_test + 3 * (size_t)C, last ? 0 : 1, cs) != 0) {
+            ctx->last_error = "mh_step_tested: draw launch failed";
+            return SEPAIHRD_E_HIP;
+        }
+        mh->staged = true;
+    } else
     HIP_TRY(hipMemcpyAsync(mh->d_test, mh->h_test, (3 * (size_t)C + (last ? 0 : CP)) * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
             return SEPAIHRD_E_HIP);
     HIP_TRY(hipEventRecord(mh->ev_test_up, cs), ctx, return SEPAIHRD_E_HIP);

@@ -183,6 +183,11 @@ struct SamplerState {
     double* wmean;  // [C][P] Welford mean of all states
     double* m2;     // [C][P][P] centred second moment, entries j <= i
     int32_t* accepted;  // [C] accepted proposals so far
+    // the chains' std::mt19937 streams when the device draws (csrc/sepaihrd_rng.inc): state words, position in the state,
+    // and the words the two continuations of the pending accept test take ([c][0] with the uniform, [c][1] without)
+    uint32_t* mt;       // [C][624]
+    int32_t* mt_idx;    // [C]
+    int32_t* mt_used;   // [C][2]
 };
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
@@ -208,6 +213,14 @@ int sampler_moments_catchup(const SamplerState& s, int row0, int n, int emit_len
 // recomputeFullCovariance as the reference writes it, two passes over states 0 .. len - 1 (the ring must hold them all)
 int sampler_full_covariance(const SamplerState& s, int len, void* stream);
 int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream);
+// std::mt19937(seed0 + chain) for every chain
+int sampler_seed_streams(const SamplerState& s, uint32_t seed0, void* stream);
+// The draws of one accept test and of the proposal after it, from every chain's stream: log(u) of the uniform the test
+// takes when log_ratio < 0, the P normals that follow it (z_uniform) and the P normals from the same position when no
+// uniform is taken (z_plain).  The stream first moves by what the PREVIOUS test's continuation used (d_flags bit 2 picks
+// it; first != 0: the stream's start, only z_plain's values are drawn and written to z_uniform).
+int sampler_draw(const SamplerState& s, const uint8_t* d_flags, int first, double* d_log_u, double* d_z_uniform, double* d_z_plain,
+                 int want_normals, void* stream);
 // per-chain summary record of SURVEY 8(e): [P means | P variances (n - 1) | best value | accepted proposals] over the
 // stored samples first_sample .. n_samples - 1, written to d_out [C][2 P + 2]
 int sampler_summary_records(const SamplerState& s, const double* d_best_lp, int first_sample, int n_samples, double* d_out, void* stream);

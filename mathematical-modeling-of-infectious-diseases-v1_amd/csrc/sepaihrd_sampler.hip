@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "sepaihrd_device.h"
+#include "sepaihrd_rng.inc"
 
 namespace sepaihrd {
 namespace {
@@ -423,9 +424,142 @@ __global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s,
     }
 }
 
+// ---- the chains' random streams on the device (csrc/sepaihrd_rng.inc has the why and the arithmetic) ----
+constexpr int MT_N = 624;
+
+// std::mt19937::seed(value): x[0] = value, x[i] = 1812433253 (x[i-1] ^ (x[i-1] >> 30)) + i; the first output twists
+__global__ void mh_seed_kernel(const SamplerState s, const uint32_t seed0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    uint32_t* g = s.mt + (size_t)c * MT_N;
+    uint32_t x = seed0 + (uint32_t)c;
+    g[0] = x;
+    for (int i = 1; i < MT_N; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+        g[i] = x;
+    }
+    s.mt_idx[c] = MT_N;
+    s.mt_used[2 * c] = 0;
+    s.mt_used[2 * c + 1] = 0;
+}
+
+// One wave per chain.  The state lives in LDS while the wave works: st[a] the state the stream is in, st[a ^ 1] the one
+// after it (the twist: word i from words i, i + 1 and the word 397 ahead -- three runs of independent words and the last).
+// Polar method in parallel: an attempt ALWAYS takes two canonicals, so attempt k of a draw reads canonicals 2k, 2k + 1 from
+// the draw's first one whatever the attempts before it decided; the lanes evaluate 64 attempts at once, a ballot ranks the
+// accepted ones, and the first ceil(P / 2) of them are the distribution's pairs (y mult, x mult) in order -- the values and
+// the number of words consumed are those of the sequential loop.
+__global__ __launch_bounds__(WAVE) void mh_draw_kernel(const SamplerState s, const uint8_t* __restrict__ flags, const int first,
+                                                       double* __restrict__ log_u, double* __restrict__ z_uniform,
+                                                       double* __restrict__ z_plain, const int want_normals) {
+    using namespace sepaihrd_rng;
+    __shared__ uint32_t st[2][MT_N];
+    __shared__ int last_lane[2];
+    const int c = blockIdx.x, lane = threadIdx.x, P = s.P;
+    uint32_t* const g = s.mt + (size_t)c * MT_N;
+    for (int i = lane; i < MT_N; i += WAVE) st[0][i] = g[i];
+    __syncthreads();
+    auto twist = [&](int from) {  // st[from] -> st[from ^ 1]
+        const uint32_t* a = st[from];
+        uint32_t* b = st[from ^ 1];
+        for (int i = lane; i < 227; i += WAVE) b[i] = mt_twist_word(a[i], a[i + 1], a[i + 397]);
+        __syncthreads();
+        for (int i = 227 + lane; i < 454; i += WAVE) b[i] = mt_twist_word(a[i], a[i + 1], b[i - 227]);
+        __syncthreads();
+        for (int i = 454 + lane; i < 623; i += WAVE) b[i] = mt_twist_word(a[i], a[i + 1], b[i - 227]);
+        __syncthreads();
+        if (lane == 0) b[623] = mt_twist_word(a[623], b[0], b[396]);
+        __syncthreads();
+    };
+    // ---- the stream moves by what the previous test's continuation took
+    int cur = 0;
+    int idx = s.mt_idx[c];
+    int consumed = first ? 0 : ((flags[c] & 4) ? s.mt_used[2 * c + 1] : s.mt_used[2 * c]);
+    bool moved_on = false;
+    while (idx + consumed >= MT_N) {
+        twist(cur);
+        cur ^= 1;
+        consumed -= MT_N - idx;
+        idx = 0;
+        moved_on = true;
+    }
+    idx += consumed;
+    if (moved_on)
+        for (int i = lane; i < MT_N; i += WAVE) g[i] = st[cur][i];
+    if (lane == 0) s.mt_idx[c] = idx;
+    // ---- look ahead from there (nothing below changes the stored stream)
+    int a = cur, apos = idx;  // the state the look-ahead is in and its position in it
+    bool have_next = false;
+    auto word = [&](int w) -> uint32_t {  // tempered output w words ahead of the look-ahead's position
+        const int q = apos + w;
+        return mt_temper(q < MT_N ? st[a][q] : st[a ^ 1][q - MT_N]);
+    };
+    const int npairs = (P + 1) / 2;
+    int have[2] = {0, 0};       // pairs found so far: [0] the continuation with the uniform in front, [1] without
+    bool done[2] = {first != 0 || !want_normals, !want_normals};
+    int used_words[2] = {2, 0};
+    double* const zdst[2] = {z_uniform + (size_t)c * P, (first ? z_uniform : z_plain) + (size_t)c * P};
+    for (int round = 0;; ++round) {
+        while (apos >= MT_N) {  // the look-ahead has left its state
+            if (!have_next) twist(a);
+            a ^= 1;
+            apos -= MT_N;
+            have_next = false;
+        }
+        if (apos + 4 * WAVE + 2 > MT_N && !have_next) { twist(a); have_next = true; }
+        if (round == 0 && lane == 0 && !first) log_u[c] = glibc_log(mt_canonical(word(0), word(1)));
+        if (done[0] && done[1]) break;
+        const uint32_t w0 = word(4 * lane), w1 = word(4 * lane + 1), w2 = word(4 * lane + 2), w3 = word(4 * lane + 3),
+                       w4 = word(4 * lane + 4), w5 = word(4 * lane + 5);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            if (done[v]) continue;  // wave-uniform
+            const double c0 = v == 0 ? mt_canonical(w2, w3) : mt_canonical(w0, w1);
+            const double c1 = v == 0 ? mt_canonical(w4, w5) : mt_canonical(w2, w3);
+            const double x = 2.0 * c0 - 1.0, y = 2.0 * c1 - 1.0;
+            const double r2 = x * x + y * y;
+            const bool ok = !(r2 > 1.0 || r2 == 0.0);
+            const unsigned long long mask = __ballot(ok);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int need = npairs - have[v];
+            if (ok && rank < need) {
+                const double mult = sqrt(-2 * glibc_log(r2) / r2);
+                const int i = 2 * (have[v] + rank);
+                zdst[v][i] = (y * mult) * 1.0 + 0.0;
+                if (i + 1 < P) zdst[v][i + 1] = (x * mult) * 1.0 + 0.0;
+                if (rank == need - 1) last_lane[v] = lane;
+            }
+            const int found = __popcll(mask);
+            if (found >= need) {
+                __syncthreads();
+                used_words[v] = (v == 0 ? 2 : 0) + 4 * WAVE * round + 4 * (last_lane[v] + 1);
+                done[v] = true;
+            } else {
+                have[v] += found;
+            }
+        }
+        apos += 4 * WAVE;
+    }
+    if (lane == 0) {
+        s.mt_used[2 * c] = first ? used_words[1] : used_words[0];
+        s.mt_used[2 * c + 1] = used_words[1];
+    }
+}
+
 }  // namespace
 
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+int sampler_seed_streams(const SamplerState& s, uint32_t seed0, void* stream) {
+    hipLaunchKernelGGL(mh_seed_kernel, dim3(blocks_for((size_t)s.C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), s, seed0);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int sampler_draw(const SamplerState& s, const uint8_t* d_flags, int first, double* d_log_u, double* d_z_uniform, double* d_z_plain,
+                 int want_normals, void* stream) {
+    hipLaunchKernelGGL(mh_draw_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, d_flags, first, d_log_u, d_z_uniform,
+                       d_z_plain, want_normals);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream) {
     hipLaunchKernelGGL(mh_propose_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, pb, d_z, d_scale);

@@ -268,6 +268,10 @@ public:
     // whole chain history, O(t P^2) per refresh and every state kept -- instead of the running co-moments the sampler
     // carries by default (O(P^2) per refresh, no history; same running mean bit for bit, covariance equal to ~1e-13)
     void setTwoPassCovariance(bool on) { two_pass_covariance_ = on; }
+    // Where the chains' std::mt19937 streams are drawn in optimizeChainsOnDevice: on the device (default: mt19937,
+    // generate_canonical, the polar method and glibc's log written out for it, csrc/sepaihrd_rng.inc -- the same values from
+    // the same stream positions) or on the host (libstdc++ itself; what sets the pace beyond a few thousand chains)
+    void setDeviceStreams(bool on) { device_streams_ = on; }
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
     // wall time of the iteration loop of the last device-resident run (proposal 1 staged .. last accept test), without
     // the set-up before it (history allocation, initial values) and the read-back after it; groups: the slowest group
@@ -285,6 +289,7 @@ private:
     std::vector<double> initial_cov_;  // row-major P x P, empty = none
     int host_threads_ = 0;
     bool two_pass_covariance_ = false;
+    bool device_streams_ = true;
     int adaptation_window_ = 0;  // ring of newest states on the device (0: adaptation period + 1, at least 128)
     double last_loop_seconds_ = 0.0;
     std::vector<double> summary_records_;  // [C][2 P + 2] of the last device-resident run

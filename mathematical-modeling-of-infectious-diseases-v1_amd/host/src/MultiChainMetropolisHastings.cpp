@@ -193,6 +193,7 @@ void MultiChainMetropolisHastings::configure(const std::map<std::string, double>
     // history instead of running co-moments, and the ring of newest states the device keeps (default: the period, >= 128)
     two_pass_covariance_ = get("two_pass_covariance", two_pass_covariance_ ? 1.0 : 0.0) != 0.0;
     adaptation_window_ = static_cast<int>(get("adaptation_window", static_cast<double>(adaptation_window_)));
+    device_streams_ = get("device_streams", device_streams_ ? 1.0 : 0.0) != 0.0;
 }
 
 OptimizationResult MultiChainMetropolisHastings::optimize(const Eigen::VectorXd& x0, IObjectiveFunction& objective,
@@ -539,7 +540,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         ch.recent.assign(1000, 0);
         if (store_samples_) ch.sample_values.push_back(ch.lp);
         traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
-        ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
+        if (!device_streams_) ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
         scale[static_cast<size_t>(c)] = ch.scale;
     }
 
@@ -574,7 +575,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             const uint8_t f = flags[static_cast<size_t>(c)];
             const bool acc = (f & 1) != 0;
             // the stream moves by what the continuation taken drew: no uniform (bit 2) -> the plain normals only
-            ch.rng.consume((f & 4) ? (drew_next ? ch.used_alt : 0) : ch.used_likely);
+            if (!device_streams_) ch.rng.consume((f & 4) ? (drew_next ? ch.used_alt : 0) : ch.used_likely);
             if (acc) {
                 ch.lp = values[static_cast<size_t>(c)];
                 ch.accepted++;
@@ -596,9 +597,14 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         }
     };
     const auto loop_begin = now();
+    if (device_streams_) check(sepaihrd_mh_seed_streams(mh, seed_), "mh_seed_streams");  // chain c: mt19937(seed + c), as the host's
     if (iterations_ > 1) {  // proposal 1: nothing to test yet
-        check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
-        z_next = sepaihrd_mh_staging_buffer(mh);
+        if (device_streams_) {
+            check(sepaihrd_mh_draw_first(mh), "mh_draw_first");
+        } else {
+            check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
+            z_next = sepaihrd_mh_staging_buffer(mh);
+        }
         check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
     }
     for (int t = 1; t < iterations_; ++t) {
@@ -616,11 +622,13 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Light& ch = chains[static_cast<size_t>(c)];
-            // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
-            ch.log_u = std::log(ch.rng.at(0));                                     // :327
-            t_log_u[c] = ch.log_u;
-            ch.used_likely = 1 + (more ? draw_normals(ch.rng, 1, &z_next[static_cast<size_t>(c) * P]) : 0);
-            if (more) ch.used_alt = draw_normals(ch.rng, 0, &z_plain[static_cast<size_t>(c) * P]);
+            if (!device_streams_) {
+                // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
+                ch.log_u = std::log(ch.rng.at(0));                                     // :327
+                t_log_u[c] = ch.log_u;
+                ch.used_likely = 1 + (more ? draw_normals(ch.rng, 1, &z_next[static_cast<size_t>(c) * P]) : 0);
+                if (more) ch.used_alt = draw_normals(ch.rng, 0, &z_plain[static_cast<size_t>(c) * P]);
+            }
             if (adapt_scale_) {
                 bool e;
                 for (int a = 0; a < 2; ++a) {
@@ -633,7 +641,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 t_scale_reject[c] = t_scale_accept[c] = ch.scale;
             }
         }
-        if (more) {
+        if (more && !device_streams_) {
             check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
             z_next = sepaihrd_mh_staging_buffer(mh);
         }

@@ -11,6 +11,7 @@
 #include "epidemic_hip/HipPosteriorEnsemble.hpp"
 #include "epidemic_hip/HipSEPAIHRD.hpp"
 #include "sepaihrd_hip.h"
+#include "sepaihrd_rng.inc"
 
 using namespace epidemic;
 
@@ -255,7 +256,7 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                 int adaptation_period, int thinning, double reg_eps, double target_acc, int adapt_scale,
                 int use_scalar_interface, int32_t* accepted, double* best_value, double* best, double* final_scale,
                 unsigned char* accept_trace, int32_t* n_samples, double* samples, double* sample_values,
-                int two_pass_covariance, double* final_cov, int adaptation_window) {
+                int two_pass_covariance, double* final_cov, int adaptation_window, int device_streams) {
     auto* h = static_cast<HostHandle*>(hv);
     try {
         const int P = static_cast<int>(h->pm->getParameterCount());
@@ -264,7 +265,8 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                       {"regularization_epsilon", reg_eps}, {"target_acceptance_rate", target_acc},
                       {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0},
-                      {"two_pass_covariance", double(two_pass_covariance)}, {"adaptation_window", double(adaptation_window)}});
+                      {"two_pass_covariance", double(two_pass_covariance)}, {"adaptation_window", double(adaptation_window)},
+                      {"device_streams", double(device_streams)}});
         mh.setSeed(seed);
         std::vector<OptimizationResult> res;
         if (use_scalar_interface == 1) {
@@ -523,6 +525,11 @@ int host_nuts_run(void* hv, const sepaihrd_problem* pb, int device, int iteratio
         g_error = e.what();
         return -1;
     }
+}
+
+// Test hook (no GPU): the device's restatement of glibc's log (csrc/sepaihrd_rng.inc), compiled for the host
+void host_glibc_log(const double* x, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = sepaihrd_rng::glibc_log(x[i]);
 }
 
 // Pure host (no GPU): exact-sort quantiles across chains of every column of a summary table, out [n_probs][width].

@@ -43,7 +43,7 @@ def load_library() -> C.CDLL:
     lib.host_apply_constraints.argtypes = [vp, C.c_int, vp, vp]
     lib.host_current_parameters.argtypes = [vp, vp]
     lib.host_mh_run.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]
+                                C.c_double, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]
     lib.host_mh_run_groups.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.host_gradient.argtypes = [vp, C.POINTER(hipabi.sepaihrd_problem), C.c_int, vp, C.c_double, vp, vp]
     lib.host_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -261,10 +261,12 @@ class HostObjective:
     def metropolis_hastings(self, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
                             thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
                             adapt_scale: bool = True, scalar_interface: bool = False, device_state: bool = False,
-                            two_pass_covariance: bool = False, want_trace: bool = True, adaptation_window: int = 0) -> dict:
+                            two_pass_covariance: bool = False, want_trace: bool = True, adaptation_window: int = 0,
+                            device_streams: bool = True) -> dict:
         """MultiChainMetropolisHastings (MetropolisHastingsSampler.cpp:201-412 for C lock-step chains): host-state loop,
         scalar interface, or (device_state) adaptation state resident in HBM.  two_pass_covariance: the reference's
-        literal covariance refresh over the whole history instead of running co-moments."""
+        literal covariance refresh over the whole history instead of running co-moments.  device_streams (device_state
+        only): the chains' mt19937 streams drawn on the device (default) or on the host."""
         x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
         Cn, P = x0.shape
         accepted = np.zeros(Cn, dtype=np.int32)
@@ -282,7 +284,8 @@ class HostObjective:
                                   accepted.ctypes.data,
                                   best_value.ctypes.data, best.ctypes.data, final_scale.ctypes.data,
                                   trace.ctypes.data if want_trace else None, C.byref(ns), samples.ctypes.data,
-                                  values.ctypes.data, int(two_pass_covariance), cov.ctypes.data, int(adaptation_window))
+                                  values.ctypes.data, int(two_pass_covariance), cov.ctypes.data, int(adaptation_window),
+                                  int(device_streams))
         if rc:
             raise RuntimeError(self.lib.host_last_error().decode())
         assert ns.value == n_s
@@ -384,3 +387,14 @@ def metropolis_hastings_group_summaries(objectives, initial, seed: int, iteratio
         raise RuntimeError(lib.host_last_error().decode())
     return {"records": records, "gathered": gathered, "samples": samples, "best_value": best_value, "accepted": accepted,
             "backend_used": int(used.value)}
+
+
+def glibc_log(x) -> np.ndarray:
+    """csrc/sepaihrd_rng.inc's restatement of glibc's log, compiled for the host (test hook)."""
+    lib = load_library()
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(a)
+    lib.host_glibc_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.host_glibc_log.restype = None
+    lib.host_glibc_log(a.ctypes.data, a.size, out.ctypes.data)
+    return out

@@ -601,6 +601,34 @@ def test_rccl_allgather_over_two_devices(mm, shipped):
         assert np.array_equal(back, want)
 
 
+@pytest.mark.parametrize("problem", ["shipped", "wide"])
+def test_streams_drawn_on_the_device_are_the_hosts(mm, oracle_py, shipped, problem):
+    """optimizeChainsOnDevice with the chains' std::mt19937 streams on the device (mt19937 state and twist, generate_canonical,
+    the polar method evaluated 64 attempts at a time, glibc's log written out: csrc/sepaihrd_rng.inc) against the same run
+    with libstdc++ drawing on the host: every output is the same bits -- accept traces, samples, values, scales, final
+    covariance.  1500 iterations per chain cross ~380 twists of the 624-word state; the 16-age problem (158 parameters:
+    79 pairs, more than 64 attempts can deliver) takes several rounds of attempts per draw.  Chain 0 against the oracle."""
+    pb = shipped
+    iters, burn, ap = 1500, 300, 100
+    if problem == "wide":
+        pb = mm.widen_age_classes(shipped, 4)
+        pb.times = pb.times[:40]
+        pb = pb.with_(obs_H=pb.obs_H[:20], obs_ICU=pb.obs_ICU[:20], obs_D=pb.obs_D[:20])
+        iters, burn, ap = 400, 50, 60
+    pb = pb.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 3, 6)
+    kw = dict(seed=4242, iterations=iters, burn_in=burn, adaptation_period=ap, thinning=25, device_state=True)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, device_streams=True, **kw)
+    host = mm.HostObjective(pb).metropolis_hastings(x0, device_streams=False, **kw)
+    assert 0.02 < dev["accept_trace"].mean() < 0.9
+    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+        assert np.array_equal(dev[k], host[k]), k
+    if problem == "shipped":
+        ref = oracle_py.Oracle(pb).metropolis_hastings(x0[0], 4242, iters, burn, adaptation_period=ap, thinning=25)
+        assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"]) and np.array_equal(dev["samples"][0], ref["samples"])
+
+
 def test_reference_constructor_argument_lists(mm, shipped):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,

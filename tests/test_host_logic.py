@@ -459,3 +459,20 @@ def test_summary_quantiles_of_gathered_chain_records(mm):
     # the Python mirror used on the torch.distributed path gives the same numbers
     import torch
     np.testing.assert_allclose(mm.parallel.ensemble_quantiles(torch.from_numpy(table), probs[:3]).numpy(), got[:3], rtol=1e-13)
+
+
+def test_device_log_restatement_equals_the_libm_of_this_image(mm):
+    """The device draws the sampler's normals and log(u) itself; the one non-IEEE step of that recipe is std::log.
+    csrc/sepaihrd_rng.inc writes out glibc's double-precision log as this image's libm evaluates it (x86-64, FMA variant);
+    compiled for the host it must give libm's bits: 400 000 arguments over the sampler's domains -- r2 in (0, 1], uniforms
+    in (0, 1), the near-1 branch [1 - 2^-4, 1 + 0x1.09p-4), tiny and subnormal values -- against math.log (libm's log)."""
+    import math
+    rs = np.random.RandomState(11)
+    u = rs.random_sample(100000)
+    u = u[u > 0]
+    xs = np.concatenate([u, u * u, 1.0 - 0.07 * u, 1.0 + 0.064 * u, np.ldexp(u, -rs.randint(0, 1000, u.size)),
+                         [1.0, 0.9375, np.nextafter(1.0, 0.0), np.nextafter(1.0, 2.0), 5e-324, 2.2250738585072014e-308, 1e-10]])
+    got = mm.hostabi.glibc_log(xs)
+    want = np.array([math.log(v) for v in xs])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.isneginf(mm.hostabi.glibc_log([0.0])[0])

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--arith", default="fma")
     ap.add_argument("--two-pass", action="store_true", help="the reference's literal refresh over the whole history")
     ap.add_argument("--workload", default="c1")
+    ap.add_argument("--host-streams", action="store_true", help="draw the chains' mt19937 streams on the host (rounds 1-2) instead of the device")
     args = ap.parse_args()
     import torch
     mm = mmid_amd_loader.load()
@@ -65,7 +66,7 @@ def main():
         t0 = time.perf_counter()
         r = host.metropolis_hastings(x0, 1, n, min(args.burn_in, n // 3), adaptation_period=args.adaptation_period,
                                      thinning=args.thinning, device_state=True, two_pass_covariance=args.two_pass,
-                                     want_trace=False)
+                                     want_trace=False, device_streams=not args.host_streams)
         wall = time.perf_counter() - t0
         stop.set()
         th.join()
@@ -82,6 +83,7 @@ def main():
     out = {"chains": C, "workload": args.workload, "arith": args.arith, "burn_in": args.burn_in,
            "adaptation_period": args.adaptation_period, "thinning": args.thinning,
            "covariance": "two-pass over the whole history" if args.two_pass else "running co-moments",
+           "streams": "host (libstdc++)" if args.host_streams else "device (csrc/sepaihrd_rng.inc)",
            "bare_evaluation_step_ms": step_ms, "device_memory_total_gb": total / 1e9, "runs": runs}
     if len(runs) >= 2:
         a, b = runs[-2], runs[-1]
