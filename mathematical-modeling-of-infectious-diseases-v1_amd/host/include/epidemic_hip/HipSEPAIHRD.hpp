@@ -273,6 +273,7 @@ public:
     // the same stream positions) or on the host (libstdc++ itself; what sets the pace beyond a few thousand chains)
     void setDeviceStreams(bool on) { device_streams_ = on; }
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
+    void setKeepAcceptTraces(bool on) { keep_traces_ = on; }  // off for long runs of many chains (65 536 x 100 000 = 6.5 GB)
     // wall time of the iteration loop of the last device-resident run (proposal 1 staged .. last accept test), without
     // the set-up before it (history allocation, initial values) and the read-back after it; groups: the slowest group
     double lastLoopSeconds() const { return last_loop_seconds_; }
@@ -290,6 +291,7 @@ private:
     int host_threads_ = 0;
     bool two_pass_covariance_ = false;
     bool device_streams_ = true;
+    bool keep_traces_ = true;  // per-iteration accept flags of every chain (acceptTraces()): C x iterations bytes on the host
     int adaptation_window_ = 0;  // ring of newest states on the device (0: adaptation period + 1, at least 128)
     double last_loop_seconds_ = 0.0;
     std::vector<double> summary_records_;  // [C][2 P + 2] of the last device-resident run

@@ -194,6 +194,7 @@ void MultiChainMetropolisHastings::configure(const std::map<std::string, double>
     two_pass_covariance_ = get("two_pass_covariance", two_pass_covariance_ ? 1.0 : 0.0) != 0.0;
     adaptation_window_ = static_cast<int>(get("adaptation_window", static_cast<double>(adaptation_window_)));
     device_streams_ = get("device_streams", device_streams_ ? 1.0 : 0.0) != 0.0;
+    keep_traces_ = get("keep_accept_traces", keep_traces_ ? 1.0 : 0.0) != 0.0;
 }
 
 OptimizationResult MultiChainMetropolisHastings::optimize(const Eigen::VectorXd& x0, IObjectiveFunction& objective,
@@ -284,7 +285,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         if (store_samples_) { r.samples.push_back(to_eigen(ch.x)); r.sampleObjectiveValues.push_back(ch.lp); }
         r.bestParameters = to_eigen(ch.x);
         r.bestObjectiveValue = ch.lp;
-        traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
+        if (keep_traces_) traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
     }
 
     for (int t = 1; t < iterations_; ++t) {
@@ -381,7 +382,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
                 ch.accepted++;
                 if (ch.lp > r.bestObjectiveValue) { r.bestObjectiveValue = ch.lp; r.bestParameters = to_eigen(ch.x); }
             }
-            traces_[static_cast<size_t>(c)].push_back(accept ? 1 : 0);
+            if (keep_traces_) traces_[static_cast<size_t>(c)].push_back(accept ? 1 : 0);
             if (adapt_scale_) {  // adaptGlobalScale :104-152
                 ch.recent.push_back(accept ? 1 : 0);
                 if (ch.recent.size() > 1000) ch.recent.pop_front();
@@ -539,7 +540,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         ch.best_x.assign(initial.begin() + static_cast<size_t>(c) * P, initial.begin() + static_cast<size_t>(c + 1) * P);
         ch.recent.assign(1000, 0);
         if (store_samples_) ch.sample_values.push_back(ch.lp);
-        traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
+        if (keep_traces_) traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
         if (!device_streams_) ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
         scale[static_cast<size_t>(c)] = ch.scale;
     }
@@ -581,7 +582,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 ch.accepted++;
                 if (f & 2) ch.best = ch.lp;  // the device compared against the same best value and keeps the state
             }
-            traces_[static_cast<size_t>(c)].push_back(acc ? 1 : 0);
+            if (keep_traces_) traces_[static_cast<size_t>(c)].push_back(acc ? 1 : 0);
             if (adapt_scale_) {
                 bool emergency_hit;
                 const double ls = next_log_scale(ch, acc, t, &emergency_hit);

@@ -266,7 +266,7 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
                       {"regularization_epsilon", reg_eps}, {"target_acceptance_rate", target_acc},
                       {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0},
                       {"two_pass_covariance", double(two_pass_covariance)}, {"adaptation_window", double(adaptation_window)},
-                      {"device_streams", double(device_streams)}});
+                      {"device_streams", double(device_streams)}, {"keep_accept_traces", accept_trace ? 1.0 : 0.0}});
         mh.setSeed(seed);
         std::vector<OptimizationResult> res;
         if (use_scalar_interface == 1) {
