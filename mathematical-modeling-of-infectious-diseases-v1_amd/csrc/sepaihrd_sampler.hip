@@ -271,11 +271,18 @@ __global__ __launch_bounds__(MOMENT_THREADS) void mh_moments_catchup_kernel(cons
     double* const m2 = s.m2 + (size_t)c * P * P;
     for (int base = 0; base < n; base += chunk_rows) {
         const int rows = min(chunk_rows, n - base);
+        // the chunk's states into LDS with every thread (coalesced rows), then thread i turns its column into deviations in
+        // place: the walk is the only sequential part and should not sit out a global-memory latency per state
+        for (int e = tid; e < rows * P; e += MOMENT_THREADS) {
+            const int r = e / P, i = e - r * P;
+            dev[e] = ring_row(s, c, row0 + base + r)[i];
+        }
+        __syncthreads();
         for (int i = tid; i < P; i += MOMENT_THREADS) {
             double mean = s.wmean[(size_t)c * P + i], sum = s.sum[(size_t)c * P + i];
             for (int r = 0; r < rows; ++r) {
                 const int row = row0 + base + r;
-                const double x = ring_row(s, c, row)[i];
+                const double x = dev[(size_t)r * P + i];
                 const double rn = 1.0 / (double)(row + 1);
                 const double d = x - mean;
                 dev[(size_t)r * P + i] = d;
