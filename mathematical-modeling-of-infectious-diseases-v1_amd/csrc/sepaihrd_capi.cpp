@@ -1015,8 +1015,7 @@ int mh_adapt_step(sepaihrd_mh* mh, double gamma, int adapt) {
         mh->pending_row.clear();
         if (mh->covariance_mode == SEPAIHRD_MH_COV_RUNNING) rc = mh_flush_moments(mh, mh->rows);
         else rc = sampler_full_covariance(mh->st, mh->rows, mh->stream);
-        if (rc == 0) rc = sampler_cholesky(mh->st, 0.0, 0, mh->stream);              // :190-197, kept on success
-        if (rc == 0) rc = sampler_cholesky(mh->st, mh->st.reg_eps, 0, mh->stream);
+        if (rc == 0) rc = sampler_cholesky_refresh(mh->st, mh->stream);  // :190-197 and :295-300, each kept on success
     }
     return rc;
 }

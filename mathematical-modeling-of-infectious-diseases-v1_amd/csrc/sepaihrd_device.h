@@ -213,6 +213,9 @@ int sampler_moments_catchup(const SamplerState& s, int row0, int n, int emit_len
 // recomputeFullCovariance as the reference writes it, two passes over states 0 .. len - 1 (the ring must hold them all)
 int sampler_full_covariance(const SamplerState& s, int len, void* stream);
 int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream);
+// the two factorisations of the adaptation-period step after a full recompute (cov, then cov + eps I, each kept on
+// success) as one: cov + eps I first, cov only if that fails -- the same factor in every case
+int sampler_cholesky_refresh(const SamplerState& s, void* stream);
 // std::mt19937(seed0 + chain) for every chain
 int sampler_seed_streams(const SamplerState& s, uint32_t seed0, void* stream);
 // The draws of one accept test and of the proposal after it, from every chain's stream: log(u) of the uniform the test

@@ -398,31 +398,41 @@ __global__ __launch_bounds__(WAVE) void mh_full_cov_kernel(const SamplerState s,
 
 // Lower Cholesky factor of cov (+ diag_add on the diagonal), one workgroup per chain, factor built in
 // LDS (packed lower triangle: P <= 200 in 160 KiB).  on_failure: 0 = leave chol untouched ("kept only on success"), 1 = 0.1 I (:242-244).
-__global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s, const double diag_add, const int on_failure) {
+// n_tries = 2: when cov + diag_add is not positive definite the factor of cov + diag_add2 is tried in the same launch.  The
+// adaptation-period step factorises cov (kept on success, :190-197) and then cov + eps I (kept on success, :295-300): the second
+// overwrites the first whenever it succeeds, so it is tried FIRST and the plain matrix only if it fails -- the same factor in
+// every case with one factorisation instead of two.
+__global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s, const double diag_add, const double diag_add2, const int n_tries,
+                                                           const int on_failure) {
     extern __shared__ double L[];  // lower triangle packed row by row: (i, j) at i (i + 1) / 2 + j, j <= i
     __shared__ int ok;
     const int c = blockIdx.x, P = s.P, tid = threadIdx.x;
     const double* A = s.cov + (size_t)c * P * P;
-    if (tid == 0) ok = 1;
-    __syncthreads();
-    for (int j = 0; j < P; ++j) {
-        const int rj = j * (j + 1) / 2;
-        if (tid == (j % WAVE)) {
-            double d = A[(size_t)j * P + j] + diag_add;
-            for (int k = 0; k < j; ++k) d -= L[rj + k] * L[rj + k];
-            if (!(d > 0.0)) ok = 0;
-            else L[rj + j] = sqrt(d);
-        }
+    for (int attempt = 0; attempt < n_tries; ++attempt) {
+        const double add = attempt == 0 ? diag_add : diag_add2;
         __syncthreads();
-        if (!ok) break;
-        const double ljj = L[rj + j];
-        for (int i = j + 1 + tid; i < P; i += WAVE) {
-            const int ri = i * (i + 1) / 2;
-            double v = A[(size_t)i * P + j];
-            for (int k = 0; k < j; ++k) v -= L[ri + k] * L[rj + k];
-            L[ri + j] = v / ljj;
-        }
+        if (tid == 0) ok = 1;
         __syncthreads();
+        for (int j = 0; j < P; ++j) {
+            const int rj = j * (j + 1) / 2;
+            if (tid == (j % WAVE)) {
+                double d = A[(size_t)j * P + j] + add;
+                for (int k = 0; k < j; ++k) d -= L[rj + k] * L[rj + k];
+                if (!(d > 0.0)) ok = 0;
+                else L[rj + j] = sqrt(d);
+            }
+            __syncthreads();
+            if (!ok) break;
+            const double ljj = L[rj + j];
+            for (int i = j + 1 + tid; i < P; i += WAVE) {
+                const int ri = i * (i + 1) / 2;
+                double v = A[(size_t)i * P + j];
+                for (int k = 0; k < j; ++k) v -= L[ri + k] * L[rj + k];
+                L[ri + j] = v / ljj;
+            }
+            __syncthreads();
+        }
+        if (ok) break;
     }
     double* dst = s.chol + (size_t)c * P * P;  // packed columns of the lower triangle (see mh_propose_kernel)
     if (ok || on_failure == 1) {
@@ -659,14 +669,20 @@ int sampler_full_covariance(const SamplerState& s, int len, void* stream) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream) {
+static int launch_cholesky(const SamplerState& s, double diag_add, double diag_add2, int n_tries, int on_failure, void* stream) {
     const size_t lds = (size_t)s.P * (s.P + 1) / 2 * sizeof(double);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&mh_cholesky_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return -3;
-    hipLaunchKernelGGL(mh_cholesky_kernel, dim3(s.C), dim3(WAVE), lds, static_cast<hipStream_t>(stream), s, diag_add, on_failure);
+    hipLaunchKernelGGL(mh_cholesky_kernel, dim3(s.C), dim3(WAVE), lds, static_cast<hipStream_t>(stream), s, diag_add, diag_add2, n_tries, on_failure);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int sampler_cholesky(const SamplerState& s, double diag_add, int on_failure, void* stream) {
+    return launch_cholesky(s, diag_add, 0.0, 1, on_failure, stream);
+}
+int sampler_cholesky_refresh(const SamplerState& s, void* stream) {
+    return launch_cholesky(s, s.reg_eps, 0.0, 2, 0, stream);
 }
 
 }  // namespace sepaihrd
