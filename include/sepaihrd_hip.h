@@ -392,6 +392,21 @@ int sepaihrd_mh_set_values(sepaihrd_mh *mh, const double *values);
  *   draw_first    the normals of proposal 1 from the start of every stream, staged for sepaihrd_mh_step. */
 int sepaihrd_mh_seed_streams(sepaihrd_mh *mh, uint32_t seed0);
 int sepaihrd_mh_draw_first(sepaihrd_mh *mh);
+/* ... and the scalar scale adaptation: adaptGlobalScale (MetropolisHastingsSampler.cpp:104-152; log_scale_, the window of the
+ * last 1000 accept flags, the emergency branches, global_scale_ = std::exp(log_scale_) with glibc's exp written out like its
+ * log) runs in the test kernel.  With the streams seeded too the sampler is SELF-CONTAINED: sepaihrd_mh_step_tested takes
+ * nothing from the caller (the test buffer is not read, no outcome is sent back per iteration, a pending test is not an
+ * error), so the caller can queue iterations as far ahead as it likes and the device goes from one evaluation to the next
+ * whatever the host is doing.  What the caller used to keep is kept here and read at the end:
+ *   keep_scale_on_device  adapt_scale / target_rate: the reference's settings; keep_trace != 0: the accept flag of every test
+ *   read_run_state        current values, best values, scales, accepted proposals, emergency shrinks per chain (any may be NULL)
+ *   read_sample_values    the chain's value at every stored sample (sampleObjectiveValues), [C][count]
+ *   read_accept_trace     [iterations - 1][C] bytes */
+int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh *mh, int adapt_scale, double target_rate, int keep_trace);
+int sepaihrd_mh_read_run_state(sepaihrd_mh *mh, double *values, double *best_values, double *scales, int32_t *accepted,
+                               int32_t *emergency);
+int sepaihrd_mh_read_sample_values(sepaihrd_mh *mh, int first, int count, double *out);
+int sepaihrd_mh_read_accept_trace(sepaihrd_mh *mh, uint8_t *out);
 double *sepaihrd_mh_test_buffer(sepaihrd_mh *mh);
 int sepaihrd_mh_step_tested(sepaihrd_mh *mh, double gamma, int adapt, int last);
 int sepaihrd_mh_fetch_test(sepaihrd_mh *mh, double *values, uint8_t *flags);

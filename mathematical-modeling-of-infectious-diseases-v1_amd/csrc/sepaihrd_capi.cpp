@@ -939,6 +939,10 @@ struct sepaihrd_mh {
     // states [mom_rows, rows) have not entered the running sums yet (see mh_moments_catchup_kernel)
     int mom_rows = 0;
     bool device_rng = false;  // the chains' mt19937 streams live on the device (sepaihrd_mh_seed_streams)
+    // a self-contained sampler lets its caller queue iterations ahead: at most ~128 of them (an event every 32 steps, four kept)
+    hipEvent_t ev_ahead[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_ahead_used[4] = {false, false, false, false};
+    long auto_steps = 0;
     int covariance_mode = SEPAIHRD_MH_COV_RUNNING;
     int iterations = 0;
     double* d_summary = nullptr;
@@ -1184,6 +1188,7 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     }
     if (mh->ev_staged) (void)hipEventDestroy(mh->ev_staged);
     for (hipEvent_t e : {mh->ev_test_up, mh->ev_tested, mh->ev_fetched, mh->ev_proposed, mh->ev_r1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : mh->ev_ahead) if (e) (void)hipEventDestroy(e);
     if (mh->h_pack) (void)hipHostFree(mh->h_pack);
     if (mh->h_fetch) (void)hipHostFree(mh->h_fetch);
     if (mh->h_test) (void)hipHostFree(mh->h_test);
@@ -1293,6 +1298,9 @@ int sepaihrd_mh_set_values(sepaihrd_mh* mh, const double* values) {
     const size_t bytes = (size_t)mh->st.C * sizeof(double);
     HIP_TRY(hipMemcpy(mh->d_lp, values, bytes, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemcpy(mh->d_best_lp, values, bytes, hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    if (mh->st.lp_store)  // the value of sample 0 (:266-268)
+        HIP_TRY(hipMemcpy2D(mh->st.lp_store, (size_t)mh->st.n_store * sizeof(double), values, sizeof(double), sizeof(double), (size_t)mh->st.C,
+                            hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
     mh->values_set = true;
     return SEPAIHRD_OK;
 }
@@ -1306,6 +1314,80 @@ int sepaihrd_mh_seed_streams(sepaihrd_mh* mh, uint32_t seed0) {
     if (sampler_seed_streams(mh->st, seed0, mh->stream) != 0) { ctx->last_error = "mh_seed_streams: launch failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     mh->device_rng = true;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh* mh, int adapt_scale, double target_rate, int keep_trace) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    SamplerState& st = mh->st;
+    const size_t C = (size_t)st.C;
+    auto dalloc = [&](void** p, size_t bytes) -> bool {
+        if (*p) return true;
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
+        mh->allocs.push_back(*p);
+        return true;
+    };
+    bool ok = dalloc((void**)&st.log_scale, C * sizeof(double)) && dalloc((void**)&st.scale, C * sizeof(double)) &&
+              dalloc((void**)&st.recent, C * 1000) && dalloc((void**)&st.recent_meta, C * 4 * sizeof(int32_t));
+    if (ok && st.n_store > 0) ok = dalloc((void**)&st.lp_store, C * st.n_store * sizeof(double));
+    if (ok && keep_trace && mh->iterations > 1) ok = dalloc((void**)&st.trace, C * (size_t)(mh->iterations - 1));
+    if (!ok) { ctx->last_error = "mh_keep_scale_on_device: device allocation failed"; return SEPAIHRD_E_HIP; }
+    std::vector<double> ones(C, 1.0);
+    HIP_TRY(hipMemset(st.log_scale, 0, C * sizeof(double)), ctx, return SEPAIHRD_E_HIP);            // log_scale_ = 0, global_scale_ = 1 (:252-253)
+    HIP_TRY(hipMemcpy(st.scale, ones.data(), C * sizeof(double), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemset(st.recent, 0, C * 1000), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemset(st.recent_meta, 0, C * 4 * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+    if (st.trace) HIP_TRY(hipMemset(st.trace, 0, C * (size_t)(mh->iterations - 1)), ctx, return SEPAIHRD_E_HIP);
+    st.adapt_scale = adapt_scale ? 1 : 0;
+    st.target_rate = target_rate;
+    st.device_scale = 1;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_run_state(sepaihrd_mh* mh, double* values, double* best_values, double* scales, int32_t* accepted, int32_t* emergency) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    const size_t C = (size_t)mh->st.C;
+    if (values) HIP_TRY(hipMemcpy(values, mh->d_lp, C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (best_values) HIP_TRY(hipMemcpy(best_values, mh->d_best_lp, C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (scales) {
+        if (!mh->st.scale) { ctx->last_error = "mh_read_run_state: the scale is not kept on the device"; return SEPAIHRD_E_INVALID_ARG; }
+        HIP_TRY(hipMemcpy(scales, mh->st.scale, C * sizeof(double), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    }
+    if (accepted) HIP_TRY(hipMemcpy(accepted, mh->st.accepted, C * sizeof(int32_t), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    if (emergency) {
+        if (!mh->st.recent_meta) { ctx->last_error = "mh_read_run_state: the scale is not kept on the device"; return SEPAIHRD_E_INVALID_ARG; }
+        HIP_TRY(hipMemcpy2D(emergency, sizeof(int32_t), mh->st.recent_meta + 3, 4 * sizeof(int32_t), sizeof(int32_t), C, hipMemcpyDeviceToHost), ctx,
+                return SEPAIHRD_E_HIP);
+    }
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_sample_values(sepaihrd_mh* mh, int first, int count, double* out) {
+    if (!mh || !out || first < 0 || count <= 0) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (!mh->st.lp_store || first + count > sepaihrd_mh_sample_count(mh)) {
+        ctx->last_error = "mh_read_sample_values: not kept (sepaihrd_mh_keep_scale_on_device) or beyond the samples stored so far";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy2D(out, (size_t)count * sizeof(double), mh->st.lp_store + first, (size_t)mh->st.n_store * sizeof(double),
+                        (size_t)count * sizeof(double), (size_t)mh->st.C, hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_accept_trace(sepaihrd_mh* mh, uint8_t* out) {
+    if (!mh || !out) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    if (!mh->st.trace) { ctx->last_error = "mh_read_accept_trace: no trace kept"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpy(out, mh->st.trace, (size_t)mh->st.C * (size_t)(mh->iterations - 1), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
     return SEPAIHRD_OK;
 }
 
@@ -1326,7 +1408,16 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     sepaihrd_ctx* ctx = mh->ctx;
     const int C = mh->st.C, P = mh->st.P;
     if (!mh->values_set) { ctx->last_error = "mh_step_tested: call sepaihrd_mh_set_values first"; return SEPAIHRD_E_INVALID_ARG; }
-    if (mh->test_pending) { ctx->last_error = "mh_step_tested: the previous test has not been fetched"; return SEPAIHRD_E_INVALID_ARG; }
+    const bool self_contained = mh->device_rng && mh->st.device_scale != 0;  // nothing of the caller's goes into the test
+    if (self_contained && (mh->auto_steps++ % 32) == 0) {
+        const int slot = (int)((mh->auto_steps / 32) % 4);
+        HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+        if (!mh->ev_ahead[slot]) HIP_TRY(hipEventCreateWithFlags(&mh->ev_ahead[slot], hipEventDisableTiming), ctx, return SEPAIHRD_E_HIP);
+        if (mh->ev_ahead_used[slot]) HIP_TRY(hipEventSynchronize(mh->ev_ahead[slot]), ctx, return SEPAIHRD_E_HIP);  // ~128 steps ago
+        HIP_TRY(hipEventRecord(mh->ev_ahead[slot], mh->stream), ctx, return SEPAIHRD_E_HIP);
+        mh->ev_ahead_used[slot] = true;
+    }
+    if (mh->test_pending && !self_contained) { ctx->last_error = "mh_step_tested: the previous test has not been fetched"; return SEPAIHRD_E_INVALID_ARG; }
     if (!last && !mh->staged && !mh->device_rng) { ctx->last_error = "mh_step_tested: no staged normals (call sepaihrd_mh_stage_normals first)"; return SEPAIHRD_E_INVALID_ARG; }
     if (mh->rows >= mh->iterations) { ctx->last_error = "mh_step_tested: more states than the sampler was created for"; return SEPAIHRD_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
@@ -1339,8 +1430,9 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
         // the caller supplies the two scale candidates only; log(u) and the normals of both continuations are drawn here,
         // from where the previous test left every chain's stream (its flags are final: the copy stream has just waited
         // for the kernel that wrote them)
-        HIP_TRY(hipMemcpyAsync(mh->d_test + C, mh->h_test + C, 2 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
-                return SEPAIHRD_E_HIP);
+        if (!self_contained)
+            HIP_TRY(hipMemcpyAsync(mh->d_test + C, mh->h_test + C, 2 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
+                    return SEPAIHRD_E_HIP);
         uint8_t* const prev_flags = reinterpret_cast<uint8_t*>(static_cast<double*>(mh->d_test_out) + C);
         if (sampler_draw(mh->st, prev_flags, 0, mh->d_test, mh->d_z_stage, mh->d_test + 3 * (size_t)C, last ? 0 : 1, cs) != 0) {
             ctx->last_error = "mh_step_tested: draw launch failed";
@@ -1367,10 +1459,12 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
         HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);  // one marker: tested AND proposed
         mh->ev_last_proposed = mh->ev_tested;
         HIP_TRY(hipStreamWaitEvent(cs, mh->ev_tested, 0), ctx, return SEPAIHRD_E_HIP);
-        HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
-                return SEPAIHRD_E_HIP);
-        HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
-        mh->test_pending = true;
+        if (!self_contained) {  // the outcome for the caller's bookkeeping (a self-contained sampler keeps its own: read at the end)
+            HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
+                    return SEPAIHRD_E_HIP);
+            HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
+            mh->test_pending = true;
+        }
         mh->proposed_once = true;
         mh->rows++;
         if (adapt == 1) mh_queue_rank1(mh, gamma);  // as mh_adapt_step: the queued update names history row rows - 1
@@ -1378,16 +1472,18 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
         mh->staged = false;
         return sepaihrd_eval_batch_device(ctx, mh->st.prop, C, mh->d_loglik, mh->d_status, nullptr, nullptr, nullptr, nullptr, st);
     }
-    int rc = sampler_accept_test(mh->st, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C, mh->d_lp,
+    int rc = sampler_accept_test(mh->st, mh->rows, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C, mh->d_lp,
                                  mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, st);
     if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipEventRecord(mh->ev_tested, st), ctx, return SEPAIHRD_E_HIP);
     // the outcome goes back on the copy stream as soon as the test has run; the main stream does not wait for it
     HIP_TRY(hipStreamWaitEvent(cs, mh->ev_tested, 0), ctx, return SEPAIHRD_E_HIP);
-    HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
-            return SEPAIHRD_E_HIP);
-    HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
-    mh->test_pending = true;
+    if (!self_contained) {
+        HIP_TRY(hipMemcpyAsync(mh->h_test_out, mh->d_test_out, (size_t)C * (sizeof(double) + 1), hipMemcpyDeviceToHost, cs), ctx,
+                return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventRecord(mh->ev_fetched, cs), ctx, return SEPAIHRD_E_HIP);
+        mh->test_pending = true;
+    }
     rc = sampler_commit_counted(mh->st, d_flags, mh->rows, 1, st);
     if (rc != 0) { ctx->last_error = "mh_step_tested: launch failed"; return SEPAIHRD_E_HIP; }
     mh->rows++;

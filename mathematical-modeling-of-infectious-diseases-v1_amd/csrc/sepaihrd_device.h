@@ -188,13 +188,26 @@ struct SamplerState {
     uint32_t* mt;       // [C][624]
     int32_t* mt_idx;    // [C]
     int32_t* mt_used;   // [C][2]
+    // adaptGlobalScale (MetropolisHastingsSampler.cpp:104-152) per chain when the device keeps it: log_scale_ / global_scale_,
+    // the window of the last 1000 accept flags as a ring with its running sum, the emergency counter
+    int32_t device_scale;   // 0: the caller supplies both candidates of the next scale with every test
+    int32_t adapt_scale;    // adapt_scale_ of the reference's settings
+    double target_rate;     // target_acceptance_rate_
+    double* log_scale;      // [C]
+    double* scale;          // [C]
+    uint8_t* recent;        // [C][1000]
+    int32_t* recent_meta;   // [C][4]: position, length, sum, emergency shrinks
+    double* lp_store;       // [C][n_store] the chain's value at every stored sample (sampleObjectiveValues)
+    uint8_t* trace;         // [iterations - 1][C] accept flags of every test, or null
 };
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
 int sampler_commit_counted(const SamplerState& s, const uint8_t* d_accept, int row, int accepted_known, void* stream);
 // the accept test on the device (flags: bit 0 accepted, bit 1 best so far, bit 2 no uniform drawn) and the proposal that
 // follows it with the normals of the continuation taken
-int sampler_accept_test(const SamplerState& s, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+// row: the state the test's outcome becomes (= the iteration t of the test); used by the device-kept scale adaptation,
+// the value store and the accept trace
+int sampler_accept_test(const SamplerState& s, const int row, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
                         const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
                         double* d_values, void* stream);
 // the three in one launch (block = chain), for iterations without a covariance refresh between commit and proposal

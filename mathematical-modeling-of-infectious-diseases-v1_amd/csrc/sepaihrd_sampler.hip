@@ -103,6 +103,48 @@ __global__ void mh_propose_kernel(const SamplerState s, const DevProblem pb, con
     }
 }
 
+// adaptGlobalScale(accepted, step) of one chain (:104-152), the window of the last 1000 flags as a ring with its running sum;
+// returns global_scale_ = exp(log_scale_) (glibc's exp, csrc/sepaihrd_rng.inc).  One thread per chain.
+__device__ __forceinline__ double adapt_global_scale(const SamplerState& s, const int c, const bool accepted, const int step) {
+    if (!s.adapt_scale) return s.scale[c];
+    int32_t* meta = s.recent_meta + 4 * (size_t)c;
+    uint8_t* ring = s.recent + 1000 * (size_t)c;
+    int pos = meta[0], len = meta[1], sum = meta[2];
+    if (len == 1000) sum -= ring[pos]; else ++len;   // push_back, pop_front beyond 1000 (:107-110)
+    ring[pos] = accepted ? 1 : 0;
+    sum += accepted ? 1 : 0;
+    pos = (pos + 1) % 1000;
+    meta[0] = pos; meta[1] = len; meta[2] = sum;
+    const double rate = (double)sum / (double)len;
+    double ls = s.log_scale[c];
+    const double target = s.target_rate;
+    if (len >= 1000 && rate < 0.001) {
+        ls -= 0.7;
+        meta[3] += 1;
+    } else if (rate < 0.02 && len >= 500) {
+        double g = 5.0 / sqrt((double)step + 1.0);
+        g = (0.3 < g) ? 0.3 : g;                     // std::min(gamma_fast, 0.3)
+        ls += g * (0.0 - target);
+    } else {
+        double g = 1.0 / sqrt((double)step + 1.0);
+        g = (0.1 < g) ? 0.1 : g;
+        ls += g * ((accepted ? 1.0 : 0.0) - target);
+    }
+    if (s.scale[c] <= 0.011 && rate > 0.15 && rate < 0.30) ls += 0.01;   // the scale BEFORE this update (:146-148)
+    ls = (2.3 < ls) ? 2.3 : ls;                      // std::max(std::min(log_scale_, 2.3), -6.9)
+    ls = (ls < -6.9) ? -6.9 : ls;
+    const double sc = sepaihrd_rng::glibc_exp(ls);
+    s.log_scale[c] = ls;
+    s.scale[c] = sc;
+    return sc;
+}
+// what else the device keeps of a test's outcome: the value of every stored sample and the accept trace
+__device__ __forceinline__ void record_outcome(const SamplerState& s, const int c, const int row, const bool accepted, const double lp_now) {
+    if (s.lp_store != nullptr && s.n_store > 0 && row % s.thinning == 0 && row / s.thinning < s.n_store)
+        s.lp_store[(size_t)c * s.n_store + row / s.thinning] = lp_now;
+    if (s.trace != nullptr && row >= 1) s.trace[(size_t)(row - 1) * s.C + c] = accepted ? 1 : 0;
+}
+
 // The accept test of MetropolisHastingsSampler::optimize (:318-331) for every chain, on the device: the evaluation's
 // value goes through safeEvaluate's rule (:65-74; a failed integration, status >= 2, counts as -1e18 like a throwing
 // objective), log_ratio = proposed - current, accepted when log_ratio >= 0 (no uniform drawn) or log(u) < log_ratio.
@@ -110,10 +152,12 @@ __global__ void mh_propose_kernel(const SamplerState s, const DevProblem pb, con
 // of the scale adaptation; the kernel picks.  flags: bit 0 accepted, bit 1 best value of the chain so far, bit 2 the test
 // took no uniform (the next normals are the other continuation's).  values = what the test compared (for the host's
 // bookkeeping, which runs while the NEXT evaluation does).  Comparisons and one subtraction: no rounding to differ in.
-__global__ void mh_accept_kernel(const int C, const double* __restrict__ loglik, const int32_t* __restrict__ status,
+__global__ void mh_accept_kernel(const SamplerState s, const int row, const double* __restrict__ loglik, const int32_t* __restrict__ status,
                                  const double* __restrict__ log_u, const double* __restrict__ scale_reject,
                                  const double* __restrict__ scale_accept, double* lp, double* best_lp, double* scale_sel,
-                                 uint8_t* flags, double* values, int32_t* accepted) {
+                                 uint8_t* flags, double* values) {
+    const int C = s.C;
+    int32_t* const accepted = s.accepted;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double v = loglik[c];
@@ -128,8 +172,9 @@ __global__ void mh_accept_kernel(const int C, const double* __restrict__ loglik,
         if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
     }
     flags[c] = f;
-    scale_sel[c] = acc ? scale_accept[c] : scale_reject[c];
+    scale_sel[c] = s.device_scale ? adapt_global_scale(s, c, acc, row) : (acc ? scale_accept[c] : scale_reject[c]);
     values[c] = v;
+    record_outcome(s, c, row, acc, lp[c]);
 }
 
 // proposal with the normals of the continuation the test took (flags bit 2) and the scale it selected
@@ -171,7 +216,8 @@ __global__ __launch_bounds__(WAVE) void mh_test_commit_propose_kernel(const Samp
             s.accepted[c] += 1;
             if (v > best_lp[c]) { best_lp[c] = v; f |= 2; }
         }
-        const double sc = acc ? scale_accept[c] : scale_reject[c];
+        const double sc = s.device_scale ? adapt_global_scale(s, c, acc, row) : (acc ? scale_accept[c] : scale_reject[c]);
+        record_outcome(s, c, row, acc, lp[c]);
         flags[c] = (uint8_t)f;
         scale_sel[c] = sc;
         values[c] = v;
@@ -598,11 +644,11 @@ int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_r
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int sampler_accept_test(const SamplerState& s, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
+int sampler_accept_test(const SamplerState& s, const int row, const double* d_loglik, const int32_t* d_status, const double* d_log_u, const double* d_scale_reject,
                         const double* d_scale_accept, double* d_lp, double* d_best_lp, double* d_scale_sel, uint8_t* d_flags,
                         double* d_values, void* stream) {
-    hipLaunchKernelGGL(mh_accept_kernel, dim3(blocks_for((size_t)s.C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), s.C, d_loglik,
-                       d_status, d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values, s.accepted);
+    hipLaunchKernelGGL(mh_accept_kernel, dim3(blocks_for((size_t)s.C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), s, row, d_loglik,
+                       d_status, d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,

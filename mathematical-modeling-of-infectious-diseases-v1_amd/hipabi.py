@@ -90,7 +90,8 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_mh_read_covariance", "sepaihrd_mh_read_proposal", "sepaihrd_mh_history_length",
     "sepaihrd_mh_sample_count", "sepaihrd_mh_read_samples", "sepaihrd_mh_read_moments", "sepaihrd_mh_summary_records",
     "sepaihrd_records_buffer", "sepaihrd_allgather_records", "sepaihrd_read_records", "sepaihrd_write_records",
-    "sepaihrd_mh_seed_streams", "sepaihrd_mh_draw_first",
+    "sepaihrd_mh_seed_streams", "sepaihrd_mh_draw_first", "sepaihrd_mh_keep_scale_on_device", "sepaihrd_mh_read_run_state",
+    "sepaihrd_mh_read_sample_values", "sepaihrd_mh_read_accept_trace",
 )
 
 _lib = None
@@ -150,6 +151,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_write_records.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.sepaihrd_mh_seed_streams.argtypes = [vp, C.c_uint32]
     lib.sepaihrd_mh_draw_first.argtypes = [vp]
+    lib.sepaihrd_mh_keep_scale_on_device.argtypes = [vp, C.c_int, C.c_double, C.c_int]
+    lib.sepaihrd_mh_read_run_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sepaihrd_mh_read_sample_values.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.sepaihrd_mh_read_accept_trace.argtypes = [vp, vp]
     lib.sepaihrd_mh_destroy.restype = None
     lib.sepaihrd_mh_destroy.argtypes = [vp]
     lib.sepaihrd_mh_evaluate_current.argtypes = [vp, vp, vp]

@@ -561,6 +561,9 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     // the scale adaptation and the normals of both continuations BEFORE the evaluation is over, so the device goes from
     // one evaluation to the next without waiting for the host; the host learns the outcome (flags, the values compared)
     // at the start of the next evaluation and does its bookkeeping for iteration t while evaluation t + 1 runs.
+    // With the streams on the device the scale adaptation goes there too (adaptGlobalScale in the test kernel): the sampler is
+    // self-contained, this loop only queues iterations, and what the host kept per chain is read back at the end
+    if (device_streams_) check(sepaihrd_mh_keep_scale_on_device(mh, adapt_scale_ ? 1 : 0, target_acceptance_rate_, keep_traces_ ? 1 : 0), "mh_keep_scale_on_device");
     check(sepaihrd_mh_set_values(mh, values.data()), "mh_set_values");
     double* const test = sepaihrd_mh_test_buffer(mh);  // [log_u C][scale if rejected C][scale if accepted C][z_plain C*P]
     double* const t_log_u = test;
@@ -608,6 +611,40 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         }
         check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
     }
+    if (device_streams_) {
+        for (int t = 1; t < iterations_; ++t)
+            check(sepaihrd_mh_step_tested(mh, 10.0 / ((t + 1) + 100.0), adapt_mode(t + 1), t + 1 < iterations_ ? 0 : 1), "mh_step_tested");
+        std::vector<double> lp_all(static_cast<size_t>(C)), best_all(static_cast<size_t>(C)), scale_all(static_cast<size_t>(C));
+        std::vector<int32_t> acc_all(static_cast<size_t>(C)), emergency_all(static_cast<size_t>(C));
+        check(sepaihrd_mh_read_run_state(mh, lp_all.data(), best_all.data(), scale_all.data(), acc_all.data(), emergency_all.data()), "mh_read_run_state");  // waits
+        last_loop_seconds_ = secs(loop_begin, now());
+        const int ns_dev = store_samples_ ? sepaihrd_mh_sample_count(mh) : 0;
+        std::vector<double> sv;
+        if (ns_dev > 0) {
+            sv.resize(static_cast<size_t>(C) * ns_dev);
+            check(sepaihrd_mh_read_sample_values(mh, 0, ns_dev, sv.data()), "mh_read_sample_values");
+        }
+        std::vector<uint8_t> tr;
+        if (keep_traces_ && iterations_ > 1) {
+            tr.resize(static_cast<size_t>(C) * (iterations_ - 1));
+            check(sepaihrd_mh_read_accept_trace(mh, tr.data()), "mh_read_accept_trace");
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int c = 0; c < C; ++c) {
+            Light& ch = chains[static_cast<size_t>(c)];
+            ch.lp = lp_all[static_cast<size_t>(c)];
+            ch.best = best_all[static_cast<size_t>(c)];
+            ch.scale = scale_all[static_cast<size_t>(c)];
+            ch.accepted = acc_all[static_cast<size_t>(c)];
+            ch.emergency = emergency_all[static_cast<size_t>(c)];
+            if (ns_dev > 0) ch.sample_values.assign(sv.begin() + static_cast<size_t>(c) * ns_dev, sv.begin() + static_cast<size_t>(c + 1) * ns_dev);
+            if (!tr.empty()) {
+                auto& out = traces_[static_cast<size_t>(c)];
+                out.resize(static_cast<size_t>(iterations_ - 1));
+                for (int t = 0; t + 1 < iterations_; ++t) out[static_cast<size_t>(t)] = tr[static_cast<size_t>(t) * C + c];
+            }
+        }
+    } else {
     for (int t = 1; t < iterations_; ++t) {
         const auto p0 = now();
         const bool more = t + 1 < iterations_;
@@ -657,6 +694,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         book(iterations_ - 1, false);
     }
     last_loop_seconds_ = secs(loop_begin, now());
+    }  // host-side streams
     {   // the best states were kept on the device
         std::vector<double> best_all(CP);
         check(sepaihrd_mh_read_best(mh, best_all.data()), "mh_read_best");

@@ -532,6 +532,11 @@ void host_glibc_log(const double* x, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = sepaihrd_rng::glibc_log(x[i]);
 }
 
+// the same for glibc's exp (the device's scale adaptation, exp(log_scale_))
+void host_glibc_exp(const double* x, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = sepaihrd_rng::glibc_exp(x[i]);
+}
+
 // Pure host (no GPU): exact-sort quantiles across chains of every column of a summary table, out [n_probs][width].
 int host_summary_quantiles(const double* table, int rows, int width, const double* probs, int n_probs, double* out) {
     try {

@@ -398,3 +398,14 @@ def glibc_log(x) -> np.ndarray:
     lib.host_glibc_log.restype = None
     lib.host_glibc_log(a.ctypes.data, a.size, out.ctypes.data)
     return out
+
+
+def glibc_exp(x) -> np.ndarray:
+    """csrc/sepaihrd_rng.inc's restatement of glibc's exp, compiled for the host (test hook)."""
+    lib = load_library()
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(a)
+    lib.host_glibc_exp.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.host_glibc_exp.restype = None
+    lib.host_glibc_exp(a.ctypes.data, a.size, out.ctypes.data)
+    return out

@@ -476,3 +476,17 @@ def test_device_log_restatement_equals_the_libm_of_this_image(mm):
     want = np.array([math.log(v) for v in xs])
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     assert np.isneginf(mm.hostabi.glibc_log([0.0])[0])
+
+
+def test_device_exp_restatement_equals_the_libm_of_this_image(mm):
+    """The self-contained sampler adapts every chain's global scale on the device: global_scale_ = std::exp(log_scale_) with
+    log_scale_ clamped to [-6.9, 2.3] (MetropolisHastingsSampler.cpp:150-151).  csrc/sepaihrd_rng.inc's restatement of
+    glibc's exp, compiled for the host, must give libm's bits over that range and well beyond it (|x| < 512), and 1 + x for
+    the tiny arguments libm short-cuts."""
+    import math
+    rs = np.random.RandomState(12)
+    xs = np.concatenate([rs.uniform(-6.9, 2.3, 300000), rs.uniform(-500.0, 500.0, 100000), rs.uniform(-1e-3, 1e-3, 20000),
+                         -6.9 + 0.01 * np.arange(921), [0.0, -0.0, -6.9, 2.3, -0.7, 1e-300, -1e-300, 2.0 ** -54, 2.0 ** -55, 511.99]])
+    got = mm.hostabi.glibc_exp(xs)
+    want = np.array([math.exp(v) for v in xs])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
