@@ -158,8 +158,8 @@ def cpu_baseline(pb, theta, budget_s):
 
 def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=None):
     """Informational, outside the timed region: the whole Adaptive-Metropolis iteration around the kernel
-    (host random streams, device-resident proposal / adaptation state and accept test, one evaluation per chain and
-    iteration), proposals per second for the step's chains.
+    (random streams, proposal / adaptation state, accept test and scale adaptation all on the device, one evaluation per
+    chain and iteration; the host queues iterations), proposals per second for the step's chains.
       * a short run (`iterations`): the iteration loop as the host library times it, MEDIAN of three runs, the better of
         one and two chain groups; the same run in strict arithmetic gives accept_trace_mismatches_vs_strict -- the
         acceptance contract of the arithmetic `value` is measured in, counted on this run's own chains;
@@ -202,7 +202,7 @@ def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=
                "acceptance": float(r["accepted"].mean() / (iters - 1)),
                "note": "ms_per_iteration = the iteration loop of a %d-iteration run timed inside the host library (median of three runs; the run's "
                        "set-up and read-back are reported separately), the better of one and two chain groups; sampler state resident in HBM, "
-                       "host keeps the mt19937 streams (DESIGN.md 6c)" % iters}
+                       "as are the chains' mt19937 streams, the accept test and the scale adaptation: the host only queues iterations (DESIGN.md 6c)" % iters}
         if pb.arith == mm.ARITH_FMA:
             strict = mm.HostObjective(pb.with_(arith=mm.ARITH_STRICT)).metropolis_hastings(theta, 1, iters, device_state=True, **kw)
             diff = strict["accept_trace"] != r1["accept_trace"]

@@ -629,6 +629,35 @@ def test_streams_drawn_on_the_device_are_the_hosts(mm, oracle_py, shipped, probl
         assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"]) and np.array_equal(dev["samples"][0], ref["samples"])
 
 
+@pytest.mark.parametrize("widen", [1e5, 300.0, 40.0])
+def test_scale_adaptation_on_the_device_through_its_rare_branches(mm, oracle_py, shipped, widen):
+    """adaptGlobalScale (MetropolisHastingsSampler.cpp:104-152) on the device, pushed through the branches an ordinary run
+    never takes: proposal sigmas widened so that nearly every proposal is rejected -- the aggressive shrink (rate < 0.02 with
+    500 outcomes), the emergency shrink (rate < 0.001 with 1000) and the clamp at log-scale -6.9; with the milder widening
+    the scale falls to the floor and the recovery rule (:146-148) can fire.  Every output equals the host-driven loop's bits,
+    chain 0 equals the oracle's."""
+    import math
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    pb.sigmas = {k: v * widen for k, v in pb.sigmas.items()}
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(shipped, 9, 4)
+    iters = 1700
+    # burn-in = the whole run: the covariance stays the widened initial one, only the scale can answer
+    kw = dict(seed=77, iterations=iters, burn_in=iters, adaptation_period=100, thinning=50, device_state=True)
+    dev = mm.HostObjective(pb).metropolis_hastings(x0, device_streams=True, **kw)
+    host = mm.HostObjective(pb).metropolis_hastings(x0, device_streams=False, **kw)
+    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+        assert np.array_equal(dev[k], host[k]), k
+    ref = oracle_py.Oracle(pb).metropolis_hastings(x0[0], 77, iters, iters, adaptation_period=100, thinning=50)
+    assert np.array_equal(dev["accept_trace"][0], ref["accept_trace"])
+    assert dev["final_scale"][0] == ref["final_scale"]
+    if widen > 1e4:
+        assert dev["accept_trace"][:, -1000:].mean() < 0.001        # the emergency branch's condition held at the end
+        assert np.all(dev["final_scale"] == math.exp(-6.9))         # ... and the clamp
+    else:
+        print("final scales", dev["final_scale"], "acceptance over the last 1000", dev["accept_trace"][:, -1000:].mean(axis=1))
+
+
 def test_reference_constructor_argument_lists(mm, shipped):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,
