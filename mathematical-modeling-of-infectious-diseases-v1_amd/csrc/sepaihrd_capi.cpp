@@ -1321,6 +1321,10 @@ int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh* mh, int adapt_scale, double ta
     if (!mh) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (mh->rows > 1) {
+        ctx->last_error = "mh_keep_scale_on_device: call it before the first iteration (the accept window and the sample values start with the run)";
+        return SEPAIHRD_E_INVALID_ARG;
+    }
     SamplerState& st = mh->st;
     const size_t C = (size_t)st.C;
     auto dalloc = [&](void** p, size_t bytes) -> bool {
@@ -1340,6 +1344,9 @@ int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh* mh, int adapt_scale, double ta
     HIP_TRY(hipMemset(st.recent, 0, C * 1000), ctx, return SEPAIHRD_E_HIP);
     HIP_TRY(hipMemset(st.recent_meta, 0, C * 4 * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
     if (st.trace) HIP_TRY(hipMemset(st.trace, 0, C * (size_t)(mh->iterations - 1)), ctx, return SEPAIHRD_E_HIP);
+    if (st.lp_store && mh->values_set && mh->rows <= 1)  // called after sepaihrd_mh_set_values: sample 0's value is the chain's current one
+        HIP_TRY(hipMemcpy2D(st.lp_store, (size_t)st.n_store * sizeof(double), mh->d_lp, sizeof(double), sizeof(double), C, hipMemcpyDeviceToDevice),
+                ctx, return SEPAIHRD_E_HIP);
     st.adapt_scale = adapt_scale ? 1 : 0;
     st.target_rate = target_rate;
     st.device_scale = 1;

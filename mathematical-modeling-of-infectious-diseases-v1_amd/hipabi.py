@@ -149,6 +149,21 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_allgather_records.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.sepaihrd_read_records.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.sepaihrd_write_records.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.sepaihrd_mh_set_values.argtypes = [vp, vp]
+    # every entry point a Python caller may reach takes its pointers as pointers (a bare int would be cut to 32 bits)
+    lib.sepaihrd_abi_version.argtypes = []
+    lib.sepaihrd_eval_batch_begin.argtypes = [vp, vp, C.c_int]
+    lib.sepaihrd_eval_batch_end.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sepaihrd_mh_stage_normals.argtypes = [vp, vp]
+    lib.sepaihrd_mh_staging_buffer.restype = vp
+    lib.sepaihrd_mh_staging_buffer.argtypes = [vp]
+    lib.sepaihrd_mh_step.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int]
+    lib.sepaihrd_mh_test_buffer.restype = vp
+    lib.sepaihrd_mh_test_buffer.argtypes = [vp]
+    lib.sepaihrd_mh_step_tested.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    lib.sepaihrd_mh_fetch_test.argtypes = [vp, vp, vp]
+    lib.sepaihrd_mh_read_best.argtypes = [vp, vp]
+    lib.sepaihrd_mh_busy.argtypes = [vp]
     lib.sepaihrd_mh_seed_streams.argtypes = [vp, C.c_uint32]
     lib.sepaihrd_mh_draw_first.argtypes = [vp]
     lib.sepaihrd_mh_keep_scale_on_device.argtypes = [vp, C.c_int, C.c_double, C.c_int]

@@ -658,6 +658,34 @@ def test_scale_adaptation_on_the_device_through_its_rare_branches(mm, oracle_py,
         print("final scales", dev["final_scale"], "acceptance over the last 1000", dev["accept_trace"][:, -1000:].mean(axis=1))
 
 
+def test_scale_on_device_in_either_order_with_set_values(mm, shipped):
+    """sepaihrd_mh_keep_scale_on_device before or after sepaihrd_mh_set_values: the value of sample 0 is the chain's current
+    value either way; after the first iteration the call is refused (the accept window starts with the run)."""
+    import ctypes as C
+    pb = shipped.with_(arith=mm.ARITH_STRICT, constraint_mode=1)
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 2, 3)
+    hip = mm.HipObjective(pb)
+    lib = hip.lib
+    P = pb.n_params
+    cov0 = np.diag(pb.sigma_array() ** 2 + 1e-6)
+    vals = np.array([1.5, -2.5, 3.25])
+    got = []
+    for order in ("before", "after"):
+        mh = mm.hipabi.mh_create(lib, hip.ctx, 3, 50, x0, cov0, thinning=5)
+        assert mh
+        if order == "before":
+            assert lib.sepaihrd_mh_keep_scale_on_device(mh, 1, C.c_double(0.234), 0) == 0
+        assert lib.sepaihrd_mh_set_values(mh, vals.ctypes.data) == 0
+        if order == "after":
+            assert lib.sepaihrd_mh_keep_scale_on_device(mh, 1, C.c_double(0.234), 0) == 0
+        out = np.full((3, 1), np.nan)
+        assert lib.sepaihrd_mh_read_sample_values(mh, 0, 1, out.ctypes.data) == 0
+        got.append(out[:, 0].copy())
+        lib.sepaihrd_mh_destroy(mh)
+    assert np.array_equal(got[0], vals) and np.array_equal(got[1], vals)
+
+
 def test_reference_constructor_argument_lists(mm, shipped):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,

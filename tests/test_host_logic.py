@@ -490,3 +490,15 @@ def test_device_exp_restatement_equals_the_libm_of_this_image(mm):
     got = mm.hostabi.glibc_exp(xs)
     want = np.array([math.exp(v) for v in xs])
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_every_declared_entry_point_has_a_ctypes_signature(mm):
+    """A ctypes call without argtypes passes a Python int as a C int: a 64-bit address handed over that way is cut to 32 bits
+    (and crashes in the library).  Every function include/sepaihrd_hip.h declares has its signature set in hipabi.py."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "sepaihrd_hip.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(sepaihrd_\w+)\s*\(", header)))
+    lib = mm.hipabi.load_library()
+    missing = [n for n in names if getattr(lib, n).argtypes is None]
+    assert not missing, missing
