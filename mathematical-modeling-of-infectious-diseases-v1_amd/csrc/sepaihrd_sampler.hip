@@ -326,7 +326,23 @@ __global__ __launch_bounds__(MOMENT_THREADS) void mh_moments_catchup_kernel(cons
         __syncthreads();
         for (int i = tid; i < P; i += MOMENT_THREADS) {
             double mean = s.wmean[(size_t)c * P + i], sum = s.sum[(size_t)c * P + i];
-            for (int r = 0; r < rows; ++r) {
+            int r = 0;
+            for (; r + 4 <= rows; r += 4) {  // the reads and the reciprocals of four states ahead of the recurrence that needs them
+                double x[4], rn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x[u] = dev[(size_t)(r + u) * P + i];
+                    rn[u] = 1.0 / (double)(row0 + base + r + u + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double d = x[u] - mean;
+                    dev[(size_t)(r + u) * P + i] = d;
+                    mean += d * rn[u];
+                    sum += x[u];
+                }
+            }
+            for (; r < rows; ++r) {
                 const int row = row0 + base + r;
                 const double x = dev[(size_t)r * P + i];
                 const double rn = 1.0 / (double)(row + 1);
@@ -346,7 +362,19 @@ __global__ __launch_bounds__(MOMENT_THREADS) void mh_moments_catchup_kernel(cons
             const int i = e / P, j = e - i * P;
             if (j > i) continue;
             double acc = m2[e];
-            for (int r = 0; r < rows; ++r) acc += wts[r] * (dev[(size_t)r * P + i] * dev[(size_t)r * P + j]);
+            // states ascending, one addition each: that chain is the recurrence's order.  The products do not depend on it:
+            // eight states' LDS reads and products are formed first, so a state costs the chain one addition, not a round trip.
+            // (What bounds the kernel after that is LDS bandwidth -- two 8-byte reads per product, nothing kept in registers;
+            // batched state reads and four interleaved entries per thread on top changed nothing: 575 against 546 us.)
+            int r = 0;
+            for (; r + 8 <= rows; r += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = wts[r + u] * (dev[(size_t)(r + u) * P + i] * dev[(size_t)(r + u) * P + j]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += t[u];
+            }
+            for (; r < rows; ++r) acc += wts[r] * (dev[(size_t)r * P + i] * dev[(size_t)r * P + j]);
             m2[e] = acc;
             if (emit) {
                 const double v = s.scaling * (acc / denom) + (i == j ? s.reg_eps : 0.0);
@@ -458,12 +486,44 @@ __global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s,
         const double add = attempt == 0 ? diag_add : diag_add2;
         __syncthreads();
         if (tid == 0) ok = 1;
+        // the matrix's lower triangle goes into L first (row-wise reads, eight rows in flight) and is factorised in place: a
+        // column step then touches LDS only, instead of one strided global read per row and column
+        for (int i0 = 0; i0 < P; i0 += 8) {
+            double a[8][(200 + WAVE - 1) / WAVE];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < (200 + WAVE - 1) / WAVE; ++q) {
+                    const int i = i0 + u, j = tid + q * WAVE;
+                    a[u][q] = (i < P && j <= i) ? A[(size_t)i * P + j] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < (200 + WAVE - 1) / WAVE; ++q) {
+                    const int i = i0 + u, j = tid + q * WAVE;
+                    if (i < P && j <= i) L[i * (i + 1) / 2 + j] = a[u][q];
+                }
+        }
         __syncthreads();
+        // v - sum_k L_ik L_jk, k ascending, one subtraction per k: the products do not depend on that chain, eight of them
+        // (and their LDS reads) are formed ahead of the subtractions that consume them
+        auto minus_dot = [&](double v, const double* __restrict__ ra, const double* __restrict__ rb, const int len) -> double {
+            int k = 0;
+            for (; k + 8 <= len; k += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ra[k + u] * rb[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v -= t[u];
+            }
+            for (; k < len; ++k) v -= ra[k] * rb[k];
+            return v;
+        };
         for (int j = 0; j < P; ++j) {
             const int rj = j * (j + 1) / 2;
             if (tid == (j % WAVE)) {
-                double d = A[(size_t)j * P + j] + add;
-                for (int k = 0; k < j; ++k) d -= L[rj + k] * L[rj + k];
+                const double d = minus_dot(L[rj + j] + add, L + rj, L + rj, j);
                 if (!(d > 0.0)) ok = 0;
                 else L[rj + j] = sqrt(d);
             }
@@ -472,9 +532,7 @@ __global__ __launch_bounds__(WAVE) void mh_cholesky_kernel(const SamplerState s,
             const double ljj = L[rj + j];
             for (int i = j + 1 + tid; i < P; i += WAVE) {
                 const int ri = i * (i + 1) / 2;
-                double v = A[(size_t)i * P + j];
-                for (int k = 0; k < j; ++k) v -= L[ri + k] * L[rj + k];
-                L[ri + j] = v / ljj;
+                L[ri + j] = minus_dot(L[ri + j], L + ri, L + rj, j) / ljj;
             }
             __syncthreads();
         }
