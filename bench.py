@@ -27,6 +27,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector FP64 peak: MI355X_MICROARCH.md gives the FP32 vector peak (157.3 TFLOP/s, SIMD-32: a wave64 instruction in
 # 2 cycles); FP64 vector instructions take 4 cycles -> half of it (78.6, AMD's public figure)
 FP64_VALU_PEAK_TFLOPS = 78.6
+PRE_WARM_SECONDS = 0.25     # the same step, untimed, before the W warm-up steps (see main)
 LOG_FLOP_EQUIV = 20         # flop-equivalents per log
 
 
@@ -286,6 +287,18 @@ def main():
                               stream=stream.cuda_stream, B=B)
 
     hip.reserve(B)
+    # Before the W warm-up steps: the device is brought out of idle (clocks, code objects, launch path) by running the same
+    # step for PRE_WARM_SECONDS -- a step is half a millisecond here, so the driver's 5 warm-up steps alone end before the
+    # card has left its idle state and the first timed launches pay for it (ms_per_step read 7 % above the kernel's own
+    # time).  Untimed, reported as config.pre_warmup_steps.
+    pre_warm_steps = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PRE_WARM_SECONDS or pre_warm_steps < 8:
+        step(pre_warm_steps)
+        pre_warm_steps += 1
+        if pre_warm_steps % 8 == 0:
+            torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
     for i in range(W):
         step(i)
     torch.cuda.synchronize(dev)
@@ -406,6 +419,7 @@ def main():
                 "workload": f"BASELINE {args.workload}: SEPAIHRD {pb.n} age groups, {solver_name}, "
                             f"{int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), {B} chains/GPU, fp64",
                 "chains_per_gpu": B, "n_params": P, "abs_err": pb.abs_err, "rel_err": pb.rel_err,
+                "pre_warmup_steps": pre_warm_steps,  # untimed, before the W warm-up steps: PRE_WARM_SECONDS of the same step
                 "arith": args.arith if args.precision == "f64" else "f32 state (fma), fp64 likelihood / time / theta",
                 "other_arith": {"mode": other if args.precision == "f64" else "f64 " + other, "steps": n_other, "ms_per_step": other_wall_ms,
                                 "ms_per_step_on_stream": other_ms,
