@@ -594,7 +594,11 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     unsigned long long acc_head = 0, acc_body = 0, acc_err = 0, acc_tail = 0;
     unsigned long long st5 = 0, st6 = 0, acc_errA = 0, acc_tailA = 0;
 #endif
+#if SEPAIHRD_ARITH_FMA
+    while (__ballot(active) != 0ull && attempts < pb.max_attempts) {  // the build-side guard rides in the loop condition
+#else
     while (__ballot(active) != 0ull) {
+#endif
         SEP_STAMP(st0);
         // min_abs(dt, t_next - t); finished chains idle with a harmless unit step
         const double cur = active ? fmin(dt, t_next - t) : 1.0;
@@ -752,6 +756,31 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         // (dt = max(dt, grown) cannot change min(dt, gap) otherwise).
         const bool need_dec = active && reject;
         const bool need_inc = active && !reject && (err < 0.5) && grow_relevant;
+#if SEPAIHRD_ARITH_FMA
+        // Tolerance build: what only a rejection or a step-size change touches lives in the block only those attempts enter (see
+        // the 16-lane form, sepaihrd_lane_split.inc: when no chain of the wave rejects or grows, cur_after = cur <= dt, so dt keeps
+        // its value, every active chain accepted and nothing can give up).  The strict build keeps the form below.
+        const bool acc = active && !reject;
+        if (__ballot(need_dec || need_inc) != 0ull) {
+            const double arg = max_moved_uniform(err, 1.0 / 3125.0);  // 5^-5: the floor of the increase rule; a rejected step has err > 1
+            const double expo = need_dec ? -1.0 / (4 - 1) : -1.0 / 5;
+            const double pw = 9.0 / 10.0 * pow_ctl(arg, expo);
+            const double f = fmax(pw, 1.0 / 5.0);  // the floor of the decrease rule; an increase has pw > 1 (err < 0.5)
+            const double cur_after = (need_dec || need_inc) ? cur * f : cur;
+            const bool rej = need_dec;
+            n_rej += rej ? 1 : 0;
+            // failure: dt = reduced current_dt; success: dt = max_abs(dt, current_dt)
+            dt = rej ? cur_after : (acc ? fmax(dt, cur_after) : dt);
+            // failed_step_checker: throws when 500 consecutive failures precede this one
+            if (rej && fails >= 500) { status = 2; active = false; }
+            fails = acc ? 0 : fails + (rej ? 1 : 0);
+        } else {
+            fails = 0;
+        }
+        n_acc += acc ? 1 : 0;
+        SEP_STAMP(st3);
+        {
+#else
         double cur_after = cur;
         if (__ballot(need_dec || need_inc) != 0ull) {
             const double arg = max_moved_uniform(err, 1.0 / 3125.0);  // 5^-5: the floor of the increase rule; a rejected step has err > 1
@@ -772,6 +801,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
             // failed_step_checker: throws when 500 consecutive failures precede this one
             if (rej && fails >= 500) { status = 2; active = false; }
             fails = acc ? 0 : fails + (rej ? 1 : 0);
+#endif
             if (acc) {
                 t += cur;
                 SEP_UNROLL
@@ -805,7 +835,9 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
                 if (k_next >= T) active = false;
                 else t_next = lds_times[k_next];
             }
+#if !SEPAIHRD_ARITH_FMA
             if (active && attempts >= pb.max_attempts) { status = 3; active = false; }
+#endif
         }
         SEP_STAMP(st4);
 #ifdef SEPAIHRD_STAMPS
@@ -816,6 +848,9 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 #endif
     }
 
+#if SEPAIHRD_ARITH_FMA
+    if (active) status = 3;  // chains still integrating when the guard ended the loop
+#endif
     // ---- 5. integrator status and step counters; the likelihood pass finishes the evaluation
     if (chain_valid && age == 0) {
         if constexpr (INLINE_LL) {  // total (SEPAIHRDObjectiveFunction.cpp:222-227)
