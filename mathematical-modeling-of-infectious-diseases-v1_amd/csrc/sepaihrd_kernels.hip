@@ -1219,7 +1219,7 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
     if constexpr (LPC == 4) {
         if (batch > 0 && lane_split_wanted(pb, batch))
             return (quad_fused_wanted() && quad_fused_lds_bytes(pb) <= QUAD_FUSED_MAX_LDS)
-                       ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true, !SEPAIHRD_ARITH_FMA>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", LL_FORM_CONSUMER_WAVES, 8 * WAVE, quad_fused_lds_bytes(pb))  // the form an evaluation without trajectories launches
+                       ? info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, true, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME "+ll", LL_FORM_CONSUMER_WAVES, 8 * WAVE, quad_fused_lds_bytes(pb))  // the form an evaluation without trajectories launches
                        : info_of(&sepaihrd_eval_quad_kernel<SOLVER, SEPAIHRD_ARITH_FMA, false>, pb, QUAD_LANES, info, SEP_QUAD_NAME, LL_FORM_SEPARATE_PASS);
     }
     // the same branches as launch_one (batch <= 0: a batch that fills the chip)
