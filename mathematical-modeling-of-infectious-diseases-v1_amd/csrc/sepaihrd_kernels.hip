@@ -88,6 +88,17 @@ struct LaneModel {  // VGPR-resident (an LDS-resident variant measured no gain a
 
 // AgeSEPAIHRDModel::computeDerivatives for this lane's age class.
 // beta_eff = beta(t) * kappa(t) of the chain.
+// Branch-probability hints of the 4-lane / 16-age time loop: they make the common path of an attempt fall through (a taken
+// branch costs a lone wave 12-15 cycles).  Tolerance build only: measured in the strict build the same hints cost 1.5-5 %
+// (c3 3.31 -> 3.44 ms, c5 28.9 -> 30.5 ms) -- its code is laid out well as it is.
+#if SEPAIHRD_ARITH_FMA
+#define SEP_RARELY(x) __builtin_expect((x), 0)
+#define SEP_MOSTLY(x) __builtin_expect((x), 1)
+#else
+#define SEP_RARELY(x) (x)
+#define SEP_MOSTLY(x) (x)
+#endif
+
 template <int LPC>
 __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[NUM_COMP],
                                     double (&dx)[NUM_COMP], double beta_eff) {
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
             const double tmin = (SOLVER == 0) ? tau[1] : tau[0];
             const double tmax = (SOLVER == 0) ? tau[6] : tau[4];
             const bool in_seg = (tmin > sch.lo) && (tmax <= sch.hi);
-            if (__ballot(active && !in_seg) != 0ull) {
+            if (SEP_RARELY(__ballot(active && !in_seg) != 0ull)) {  // rare: the common path falls through
                 // some chain's step leaves its cached segment: look the stages up again (rare)
                 int c_lo, c_hi;
                 segment_index2(sch, pb.nm_pad, tmin, tmax, c_lo, c_hi);
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         // the 16-lane form, sepaihrd_lane_split.inc: when no chain of the wave rejects or grows, cur_after = cur <= dt, so dt keeps
         // its value, every active chain accepted and nothing can give up).  The strict build keeps the form below.
         const bool acc = active && !reject;
-        if (__ballot(need_dec || need_inc) != 0ull) {
+        if (SEP_RARELY(__ballot(need_dec || need_inc) != 0ull)) {
             const double arg = max_moved_uniform(err, 1.0 / 3125.0);  // 5^-5: the floor of the increase rule; a rejected step has err > 1
             const double expo = need_dec ? -1.0 / (4 - 1) : -1.0 / 5;
             const double pw = 9.0 / 10.0 * pow_ctl(arg, expo);
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         {
 #else
         double cur_after = cur;
-        if (__ballot(need_dec || need_inc) != 0ull) {
+        if (SEP_RARELY(__ballot(need_dec || need_inc) != 0ull)) {
             const double arg = max_moved_uniform(err, 1.0 / 3125.0);  // 5^-5: the floor of the increase rule; a rejected step has err > 1
             const double expo = need_dec ? -1.0 / (4 - 1) : -1.0 / 5;
             const double pw = 9.0 / 10.0 * pow_ctl(arg, expo);
@@ -815,7 +826,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
             // less_with_sign(t, t_next, dt): t_next - t > epsilon
             const bool reached = acc && !((t_next - t) > DBL_EPSILON);
             if constexpr (INLINE_LL) {
-                if (__ballot(reached) != 0ull) {
+                if (SEP_MOSTLY(__ballot(reached) != 0ull)) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record requested a step ago
                     const double2 ra = *reinterpret_cast<const double2*>(lds_rec + 2 * lane);
                     const double2 rb = *reinterpret_cast<const double2*>(lds_rec + 2 * WAVE + 2 * lane);
