@@ -43,3 +43,21 @@ def test_no_dpp_read_hazard_in_the_shipped_kernels():
     for listing in chk.build_listings():
         violations, n = chk.check(listing)
         assert n > 100 and violations == [], listing
+
+
+def test_strict_headline_kernel_sits_in_its_fast_code_placement():
+    """A lone wave is fed ~1.9 bytes of instructions per cycle: a run of 8-byte encodings that starts 4 bytes off an 8-byte
+    boundary issues every 5.2 cycles instead of every 4.2-4.3 (tools/ubench/phase.hip).  The strict build's RK body is almost
+    purely 8-byte VOP3 encodings, and every 4-byte encoding in front of it flips its phase: the build has a fast and a slow
+    placement 6-8 % apart (0.878 against 0.935 ms per 4096-chain evaluation), one s_nop at the loop head switches between them
+    (-DSEPAIHRD_PHASE_NOPS_HEAD=1).  tools/check_code_phase.py reads the placement off the disassembly: in the fast one 27 %
+    of the body's 8-byte encodings inside runs start 4 bytes off, in the slow one 73 %.  If this fails after a change to the
+    loop, add (or remove) one pad at the loop head of the strict build and look again."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_code_phase", os.path.join(ROOT, "tools", "check_code_phase.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    res = chk.analyse("strict")
+    body = [v for k, v in res.items() if "ILi0ELi0ELb1ELb0EE" in k]   # Dopri5, strict, fused, no trajectory: the headline's strict twin
+    assert len(body) == 1 and body[0]["wide"] > 400, res.keys()
+    assert body[0]["share_off_in_runs"] < 0.5, body[0]
