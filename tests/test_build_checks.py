@@ -58,6 +58,9 @@ def test_strict_headline_kernel_sits_in_its_fast_code_placement():
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     res = chk.analyse("strict")
-    body = [v for k, v in res.items() if "ILi0ELi0ELb1ELb0EE" in k]   # Dopri5, strict, fused, no trajectory: the headline's strict twin
-    assert len(body) == 1 and body[0]["wide"] > 400, res.keys()
-    assert body[0]["share_off_in_runs"] < 0.5, body[0]
+    # With the pads chosen on this figure (SEPAIHRD_STRICT_STAGE_PADS / SEPAIHRD_STRICT_HEAD_PADS_CK in sepaihrd_lane_split.inc:
+    # a search over the pad masks with this script, the best ones confirmed on the GPU, 0.879 -> 0.855 ms) 2-3 % are off phase.
+    for key in ("ILi0ELi0ELb1ELb0EE", "ILi1ELi0ELb1ELb0EE"):   # Dopri5 / Cash-Karp, strict, fused, no trajectory
+        body = [v for k, v in res.items() if key in k]
+        assert len(body) == 1 and body[0]["wide"] > 400, res.keys()
+        assert body[0]["share_off_in_runs"] < 0.15, (key, body[0])
