@@ -281,6 +281,15 @@ __device__ __forceinline__ void stage_term(double& acc, double vecA, double vecB
 
 // The RK stages of one attempt with the row-coefficient vectors: k2..k7 (k1 for Cash-Karp), the new state and the
 // error estimate.  rhs_call(x_in, k_out, beta_kappa) evaluates the right-hand side.  N = values per lane.
+// Phase pads of the 16-age RK body of the tolerance build (N = 11 values per lane, one wave per SIMD: configs[4]; DESIGN.md 4,
+// "The strict build's two speeds"): one 4-byte s_nop in front of (even bits) or behind (odd bits) the RHS of stage i / 2 when the
+// bit is set in SEPAIHRD_FMA16_STAGE_PADS, tied to a value of that point so that it stays where it is written.  The mask is chosen
+// with tools/check_code_phase.py (8-byte encodings off phase at 0.9 cycles, a pad at 4.3) and confirmed on the GPU.
+#ifndef SEPAIHRD_FMA16_STAGE_PADS
+#define SEPAIHRD_FMA16_STAGE_PADS 194  // greedy front-to-back search: 231 -> 180 of the body's 458 eight-byte encodings off phase, c5 18.40 -> 18.25 ms
+#endif
+#define SEP_ROW_STAGE_PAD(i, v) do { if constexpr (N == NUM_COMP) { if ((SEPAIHRD_FMA16_STAGE_PADS >> (i)) & 1) asm volatile("s_nop 0" : "+v"(v)); } } while (0)
+
 template <int SOLVER, int N, class RHS>
 __device__ __forceinline__ void rk_stages_row_coef(const double cur, const double vecA, const double vecB, const double (&x)[N],
                                                    double (&k1)[N], double (&k2)[N], double (&k3)[N], double (&k4)[N], double (&k5)[N],
@@ -290,29 +299,35 @@ __device__ __forceinline__ void rk_stages_row_coef(const double cur, const doubl
         if (SOLVER == 0) {
             { const double f1 = cur * dp::b21;
               SEP_UNROLL for (int c = 0; c < N; ++c) xt[c] = fma(f1, k1[c], x[c]);
-              rhs_call(xt, k2, bks[1]); }
+              SEP_ROW_STAGE_PAD(0, xt[0]); rhs_call(xt, k2, bks[1]); }
+            SEP_ROW_STAGE_PAD(1, k2[0]);
             { const double f1 = cur * dp::b31;
               SEP_UNROLL for (int c = 0; c < N; ++c) { xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B32>(xt[c], vecA, vecB, k2[c]); }
-              rhs_call(xt, k3, bks[2]); }
+              SEP_ROW_STAGE_PAD(2, xt[0]); rhs_call(xt, k3, bks[2]); }
+            SEP_ROW_STAGE_PAD(3, k3[0]);
             { const double f1 = cur * dp::b41;
               SEP_UNROLL for (int c = 0; c < N; ++c) {
                   xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B42>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B43>(xt[c], vecA, vecB, k3[c]); }
-              rhs_call(xt, k4, bks[3]); }
+              SEP_ROW_STAGE_PAD(4, xt[0]); rhs_call(xt, k4, bks[3]); }
+            SEP_ROW_STAGE_PAD(5, k4[0]);
             { const double f1 = cur * dp::b51;
               SEP_UNROLL for (int c = 0; c < N; ++c) {
                   xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B52>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B53>(xt[c], vecA, vecB, k3[c]);
                   stage_term<QD_B54>(xt[c], vecA, vecB, k4[c]); }
-              rhs_call(xt, k5, bks[4]); }
+              SEP_ROW_STAGE_PAD(6, xt[0]); rhs_call(xt, k5, bks[4]); }
+            SEP_ROW_STAGE_PAD(7, k5[0]);
             { const double f1 = cur * dp::b61;
               SEP_UNROLL for (int c = 0; c < N; ++c) {
                   xt[c] = fma(f1, k1[c], x[c]); stage_term<QD_B62>(xt[c], vecA, vecB, k2[c]); stage_term<QD_B63>(xt[c], vecA, vecB, k3[c]);
                   stage_term<QD_B64>(xt[c], vecA, vecB, k4[c]); stage_term<QD_B65>(xt[c], vecA, vecB, k5[c]); }
-              rhs_call(xt, k6, bks[5]); }
+              SEP_ROW_STAGE_PAD(8, xt[0]); rhs_call(xt, k6, bks[5]); }
+            SEP_ROW_STAGE_PAD(9, k6[0]);
             { const double f1 = cur * dp::c1;
               SEP_UNROLL for (int c = 0; c < N; ++c) {
                   xnew[c] = fma(f1, k1[c], x[c]); stage_term<QD_C3>(xnew[c], vecA, vecB, k3[c]); stage_term<QD_C4>(xnew[c], vecA, vecB, k4[c]);
                   stage_term<QD_C5>(xnew[c], vecA, vecB, k5[c]); stage_term<QD_C6>(xnew[c], vecA, vecB, k6[c]); }
-              rhs_call(xnew, k7, bks[6]); }
+              SEP_ROW_STAGE_PAD(10, xnew[0]); rhs_call(xnew, k7, bks[6]); }
+            SEP_ROW_STAGE_PAD(11, k7[0]);
             // e1 k1 + e3 k3 + ...: of two leading products the contraction pass rounds the second and fuses the first
             // (see the 4-lane kernel's listing); written out so that it does not depend on the pass
             { const double e1 = cur * dp::dc1, e3 = cur * dp::dc3;
