@@ -288,7 +288,10 @@ __device__ __forceinline__ void stage_term(double& acc, double vecA, double vecB
 #ifndef SEPAIHRD_FMA16_STAGE_PADS
 #define SEPAIHRD_FMA16_STAGE_PADS 194  // greedy front-to-back search: 231 -> 180 of the body's 458 eight-byte encodings off phase, c5 18.40 -> 18.25 ms
 #endif
-#define SEP_ROW_STAGE_PAD(i, v) do { if constexpr (N == NUM_COMP) { if ((SEPAIHRD_FMA16_STAGE_PADS >> (i)) & 1) asm volatile("s_nop 0" : "+v"(v)); } } while (0)
+#ifndef SEPAIHRD_FMA3_STAGE_PADS   // the same pad points in the 16-lane form's body (N = 3 values per lane)
+#define SEPAIHRD_FMA3_STAGE_PADS 0
+#endif
+#define SEP_ROW_STAGE_PAD(i, v) do { if ((((N == NUM_COMP) ? SEPAIHRD_FMA16_STAGE_PADS : (N == 3) ? SEPAIHRD_FMA3_STAGE_PADS : 0) >> (i)) & 1) asm volatile("s_nop 0" : "+v"(v)); } while (0)
 
 template <int SOLVER, int N, class RHS>
 __device__ __forceinline__ void rk_stages_row_coef(const double cur, const double vecA, const double vecB, const double (&x)[N],
