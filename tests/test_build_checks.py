@@ -64,3 +64,31 @@ def test_strict_headline_kernel_sits_in_its_fast_code_placement():
         body = [v for k, v in res.items() if key in k]
         assert len(body) == 1 and body[0]["wide"] > 400, res.keys()
         assert body[0]["share_off_in_runs"] < 0.15, (key, body[0])
+
+
+def test_assembly_phase_pass_aligns_the_runs_of_the_tolerance_bodies(tmp_path):
+    """csrc/phase_pass.py (the build's pass over the device assembly, csrc/Makefile): on a fresh `hipcc -S` listing of the
+    tolerance build its output assembles, holds the same instructions but for `_e32` -> `_e64` re-encodings and `s_nop 0` pads,
+    and leaves at most 30 of the 16-lane common body's ~190 eight-byte encodings off phase (80 without it; none inside a run
+    of three or more)."""
+    import importlib.util, re, subprocess
+    spec = importlib.util.spec_from_file_location("check_code_phase", os.path.join(ROOT, "tools", "check_code_phase.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    csrc = os.path.join(ROOT, "mathematical-modeling-of-infectious-diseases-v1_amd", "csrc")
+    src, dst, obj = str(tmp_path / "dev.s"), str(tmp_path / "phased.s"), str(tmp_path / "phased.o")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    "-ffp-contract=fast", "-DSEPAIHRD_ARITH_FMA=1", "--cuda-device-only", "-S", os.path.join(csrc, "sepaihrd_kernels.hip"), "-o", src],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run(["python3", os.path.join(csrc, "phase_pass.py"), src, dst], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([chk.LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dst, "-o", obj], check=True)
+    # the same instruction stream: drop the pads, undo the re-encodings, compare line by line
+    a = [l for l in open(src).read().split("\n")]
+    b = [l.replace("_e64", "_e32") for l in open(dst).read().split("\n") if l != "\ts_nop 0"]
+    a_n = [l.replace("_e64", "_e32") for l in a if l != "\ts_nop 0"]
+    assert a_n == b
+    dis = subprocess.run([chk.LLVM + "/llvm-objdump", "-d", obj], check=True, capture_output=True, text=True).stdout
+    bodies = [chk.phase_report(blk) for name, ins in chk.kernels(dis).items() if "sepaihrd_eval_quad_kernelILi0ELi1ELb1ELb0EE" in name
+              for blk in chk.body_blocks(ins, 250)]
+    common = max(bodies, key=lambda r: r["instructions"])
+    assert common["wide"] > 150 and common["wide_off"] <= 30 and common["wide_off_in_runs"] == 0, common
