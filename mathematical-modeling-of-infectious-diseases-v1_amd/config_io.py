@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import csv
 import os
+import re
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -93,13 +94,192 @@ def read_settings(path: str) -> Dict[str, float]:
     return {tok[0]: float(tok[1]) for tok in _config_lines(path) if len(tok) >= 2}
 
 
+class CSVReadError(ValueError):
+    """epidemic::CSVReadException (include/exceptions/CSVReadException.hpp): `kind` is the name of its ErrorType."""
+
+    def __init__(self, kind: str, message: str):
+        super().__init__(f"{kind}: {message}")
+        self.kind = kind
+
+
+class FileIOError(OSError):
+    """epidemic::FileIOException."""
+
+
+class DataFormatError(ValueError):
+    """epidemic::DataFormatException."""
+
+
+_STOD_PREFIX = re.compile(r"\s*[+-]?(?:(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?|inf(?:inity)?|nan)", re.IGNORECASE)
+
+
+def _stod(cell: str) -> float:
+    """std::stod: leading whitespace, then the longest numeric prefix; ValueError when there is none."""
+    m = _STOD_PREFIX.match(cell)
+    if not m:
+        raise ValueError(cell)
+    return float(m.group(0))
+
+
 def read_matrix_csv(path: str, rows: int, cols: int) -> np.ndarray:
-    with open(path, "r") as fh:
-        data = [[float(v) for v in line.strip().split(",")] for line in fh if line.strip()]
-    m = np.array(data, dtype=np.float64)
-    if m.shape != (rows, cols):
-        raise ValueError(f"contact matrix shape {m.shape}, expected {(rows, cols)}")
-    return m
+    """readMatrixFromCSV (src/utils/ReadContactMatrix.cpp:8-83): leading ``//`` lines are skipped, the next line is row 1
+    (line i, field j -> M(i, j)), empty lines between later rows are skipped, fields and rows beyond rows x cols are
+    not looked at.  Errors carry the reference's CSVReadException::ErrorType as `kind`: FileOpenError, NotEnoughRows,
+    NotEnoughColumns, InvalidNumberFormat (tests/utils/ReadContactMatrixTests.cpp:57-137)."""
+    try:
+        with open(path, "rb") as fh:
+            lines = fh.read().decode("utf-8", "replace").split("\n")
+    except OSError:
+        raise CSVReadError("FileOpenError", path) from None
+    if lines and lines[-1] == "":
+        lines.pop()  # std::getline does not deliver an empty last line after the final newline
+    k = 0
+    while k < len(lines) and lines[k] != "" and lines[k][:2] == "//":
+        k += 1
+    if k >= len(lines):
+        raise CSVReadError("NotEnoughRows", "No data rows found in file: " + path)
+    mat = np.zeros((rows, cols))
+
+    def parse_row(i: int, line: str) -> None:
+        cells = line.split(",") if line != "" else []
+        if line.endswith(","):
+            cells.pop()  # std::getline(ss, cell, ',') does not deliver an empty field behind the last comma
+        for j in range(cols):
+            if j >= len(cells):
+                raise CSVReadError("NotEnoughColumns", f"row {i + 1} in {path}")
+            try:
+                mat[i, j] = _stod(cells[j])
+            except ValueError:
+                raise CSVReadError("InvalidNumberFormat", f"row {i + 1}, column {j + 1}: '{cells[j]}' in {path}") from None
+
+    parse_row(0, lines[k])
+    k += 1
+    i = 1
+    while i < rows:
+        if k >= len(lines):
+            raise CSVReadError("NotEnoughRows", f"expected {rows} rows, found {i} in {path}")
+        line = lines[k]
+        k += 1
+        if line == "":
+            continue
+        parse_row(i, line)
+        i += 1
+    return mat
+
+
+def join_paths(path1: str, path2: str) -> str:
+    """FileUtils::joinPaths (src/utils/FileUtils.cpp:62-72): one leading '/' of path2 dropped, then
+    (path1 / path2).lexically_normal()."""
+    if path2 == "":
+        return path1
+    rel = path2[1:] if path2.startswith("/") else path2
+    if path1 == "":
+        joined = rel
+    elif path1.endswith("/"):
+        joined = path1 + rel
+    else:
+        joined = path1 + "/" + rel
+    if joined == "":
+        return ""
+    out = os.path.normpath(joined)
+    # lexically_normal keeps a trailing separator as "dir/"; normpath drops it, and turns "" into "."
+    if joined.endswith("/") and out != "/":
+        out += "/"
+    return out
+
+
+FILEUTILS_AGE_VECTORS = ("p", "h", "icu", "d_H", "d_ICU")
+FILEUTILS_SCALARS = ("beta", "theta", "sigma", "gamma_p", "gamma_A", "gamma_I", "gamma_H", "gamma_ICU",
+                     "contact_matrix_scaling_factor")
+_ISTREAM_DOUBLE = re.compile(r"[+-]?(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?")
+
+
+class _IStream:
+    """The part of std::istringstream these readers use: `>> word` and `>> double` (whitespace skipped, the longest
+    numeric prefix taken, the rest left in the stream)."""
+
+    def __init__(self, text: str):
+        self.s, self.pos = text, 0
+
+    def _skip(self) -> None:
+        while self.pos < len(self.s) and self.s[self.pos] in " \t\n\r\f\v":
+            self.pos += 1
+
+    def at_end(self) -> bool:
+        self._skip()
+        return self.pos >= len(self.s)
+
+    def word(self):
+        self._skip()
+        start = self.pos
+        while self.pos < len(self.s) and self.s[self.pos] not in " \t\n\r\f\v":
+            self.pos += 1
+        return self.s[start:self.pos] or None
+
+    def double(self):
+        self._skip()
+        m = _ISTREAM_DOUBLE.match(self.s, self.pos)
+        if not m:
+            return None
+        self.pos = m.end()
+        return float(m.group(0))
+
+
+def read_sepaihrd_parameters_fileutils(path: str, num_age_classes: int) -> dict:
+    """FileUtils::readSEPAIHRDParameters (src/utils/FileUtils.cpp:74-196), the older of the reference's two parameter
+    readers and the one its tests pin (tests/utils/FileUtilsTests.cpp:146-320): ``name value...`` lines, `#` starts a
+    comment line, the age vectors p / h / icu / d_H / d_ICU take exactly num_age_classes values, kappa_end_times /
+    kappa_values take any number, everything else exactly one; the last occurrence of a name wins; unknown scalar names
+    are ignored with a warning.  Errors: FileIOError (file cannot be opened) and DataFormatError with the reference's
+    message texts."""
+    where = "FileUtils::readSEPAIHRDParameters"
+    try:
+        fh = open(path, "r")
+    except OSError:
+        raise FileIOError(f"{where}: Unable to open parameters file: {path}") from None
+    out: dict = {name: np.zeros(num_age_classes) for name in FILEUTILS_AGE_VECTORS}
+    out["kappa_end_times"], out["kappa_values"] = [], []
+    with fh:
+        for line_number, raw in enumerate(fh, start=1):
+            line = raw.strip(" \t\n\r\f\v")
+            if not line or line[0] == "#":
+                continue
+            iss = _IStream(line)
+            name = iss.word()
+            if name in FILEUTILS_AGE_VECTORS:
+                for i in range(num_age_classes):
+                    v = iss.double()
+                    if v is None:
+                        raise DataFormatError(f"{where}: Error reading value for age class {i} of parameter '{name}' on line {line_number}")
+                    out[name][i] = v
+                if iss.double() is not None:
+                    raise DataFormatError(f"{where}: Too many values provided for age-specific parameter '{name}' on line "
+                                          f"{line_number}. Expected {num_age_classes} values.")
+            elif name in ("kappa_end_times", "kappa_values"):
+                vals = []
+                while True:
+                    v = iss.double()
+                    if v is None:
+                        break
+                    vals.append(v)
+                if not iss.at_end():  # iss.fail() && !iss.eof()
+                    raise DataFormatError(f"{where}: Invalid non-numeric data found for '{name}' on line {line_number}")
+                out[name] = vals
+            else:
+                v = iss.double()
+                if v is None:
+                    found = iss.word()
+                    if found is None:
+                        raise DataFormatError(f"{where}: Missing scalar value for parameter '{name}' on line {line_number}")
+                    raise DataFormatError(f"{where}: Error reading scalar value for parameter '{name}' on line {line_number}. Found: '{found}'")
+                if iss.double() is not None:
+                    raise DataFormatError(f"{where}: Too many values provided for scalar parameter '{name}' on line {line_number}. Expected 1 value.")
+                if name in FILEUTILS_SCALARS:
+                    out[name] = v
+    if out["kappa_end_times"] and out["kappa_values"] and len(out["kappa_end_times"]) != len(out["kappa_values"]):
+        raise DataFormatError(f"{where}: Mismatch between number of kappa_end_times ({len(out['kappa_end_times'])}) and "
+                              f"kappa_values ({len(out['kappa_values'])}) read from file: {path}")
+    return out
 
 
 @dataclass
@@ -115,37 +295,120 @@ class CalibrationData:
     cumulative_hospitalizations: np.ndarray
     cumulative_icu: np.ndarray
     population: np.ndarray
+    num_age_classes: int = 4
 
     @property
     def num_data_points(self) -> int:
         return len(self.dates)
 
+    @classmethod
+    def from_matrices(cls, new_confirmed, new_hospitalizations, new_icu, new_deaths, population, cum_confirmed0, cum_deaths0,
+                      cum_hospitalizations0, cum_icu0, num_age_classes: int) -> "CalibrationData":
+        """The reference's matrix constructor (src/utils/GetCalibrationData.cpp:24-89; argument order as there): the
+        cumulative matrices start at the given day-0 rows and add the PREVIOUS day's increments, dates are
+        ``mock_date_i``; size mismatches are std::invalid_argument (ValueError)."""
+        n = int(num_age_classes)
+        mats = [np.asarray(m, dtype=np.float64).reshape(-1, n) if np.asarray(m).size else np.zeros((0, n))
+                for m in (new_confirmed, new_hospitalizations, new_icu, new_deaths)] if n > 0 else []
+        if n <= 0:
+            raise ValueError("Number of age classes must be positive.")
+        pop = np.asarray(population, dtype=np.float64).ravel()
+        if pop.size != n:
+            raise ValueError("Population vector size mismatch with num_age_classes.")
+        for m in (new_confirmed, new_hospitalizations, new_icu, new_deaths):
+            m = np.asarray(m)
+            if m.ndim != 2 or m.shape[1] != n:
+                raise ValueError("Incidence data matrix column count mismatch with num_age_classes.")
+        row0 = [np.asarray(v, dtype=np.float64).ravel() for v in (cum_confirmed0, cum_deaths0, cum_hospitalizations0, cum_icu0)]
+        if any(v.size != n for v in row0):
+            raise ValueError("Initial cumulative data vector size mismatch with num_age_classes.")
+        new_c, new_h, new_i, new_d = mats
+        T = new_c.shape[0]
 
-def read_calibration_csv(path: str, start_date: str, end_date: str) -> CalibrationData:
-    cols = {
-        "new_confirmed": "new_confirmed_", "new_deaths": "new_deceased_",
-        "new_hospitalizations": "new_hospitalized_patients_", "new_icu": "new_intensive_care_patients_",
-        "cumulative_confirmed": "cumulative_confirmed_", "cumulative_deaths": "cumulative_deceased_",
-        "cumulative_hospitalizations": "cumulative_hospitalized_patients_",
-        "cumulative_icu": "cumulative_intensive_care_patients_",
-    }
-    acc: Dict[str, list] = {k: [] for k in cols}
-    dates: List[str] = []
-    population = None
-    with open(path, newline="") as fh:
-        for row in csv.DictReader(fh):
-            d = row["date"]
+        def cumulative(new, first):
+            out = np.zeros((T, n))
+            for i in range(T):
+                if i == 0:
+                    out[0] = first
+                elif i - 1 < new.shape[0]:
+                    out[i] = out[i - 1] + new[i - 1]
+                else:
+                    out[i] = out[i - 1]
+            return out
+
+        return cls(dates=[f"mock_date_{i}" for i in range(T)], new_confirmed=new_c, new_deaths=new_d,
+                   new_hospitalizations=new_h, new_icu=new_i, cumulative_confirmed=cumulative(new_c, row0[0]),
+                   cumulative_deaths=cumulative(new_d, row0[1]), cumulative_hospitalizations=cumulative(new_h, row0[2]),
+                   cumulative_icu=cumulative(new_i, row0[3]), population=pop, num_age_classes=n)
+
+    def initial_active_cases(self) -> np.ndarray:
+        """getInitialActiveCases (:101-106): row 0 of the cumulative confirmed cases."""
+        if self.cumulative_confirmed.shape[0] == 0:
+            raise RuntimeError("Cannot get initial active cases: cumulative_confirmed_cases data is empty.")
+        return self.cumulative_confirmed[0].copy()
+
+
+CSV_COLUMN_PREFIXES = {
+    "new_confirmed": "new_confirmed_", "new_deaths": "new_deceased_",
+    "new_hospitalizations": "new_hospitalized_patients_", "new_icu": "new_intensive_care_patients_",
+    "cumulative_confirmed": "cumulative_confirmed_", "cumulative_deaths": "cumulative_deceased_",
+    "cumulative_hospitalizations": "cumulative_hospitalized_patients_",
+    "cumulative_icu": "cumulative_intensive_care_patients_",
+}
+
+
+def read_calibration_csv(path: str, start_date: str = "", end_date: str = "") -> CalibrationData:
+    """CalibrationData(filename, start, end) (src/utils/GetCalibrationData.cpp:15-22,236-401): columns found by NAME in the
+    header (a missing one is a runtime_error naming it), rows kept when start <= date <= end as strings (an empty bound is
+    open), population from the first kept row; an unreadable file, a header-only file or an empty date window is the
+    constructor's runtime_error "Failed to initialize CalibrationData from file"."""
+    fail = RuntimeError("Failed to initialize CalibrationData from file: " + path)
+    try:
+        fh = open(path, newline="")
+    except OSError:
+        raise fail from None
+    with fh:
+        header = fh.readline()
+        if header == "":
+            raise fail
+        index = {}
+        for k, name in enumerate(header.rstrip("\r\n").split(",")):
+            index[name] = k  # a repeated name: the last one wins (std::map assignment)
+        def col(name):
+            if name not in index:
+                raise RuntimeError("Missing required column: " + name)
+            return index[name]
+        date_idx = col("date")
+        idx = {key: [col(prefix + band) for band in AGE_BANDS] for key, prefix in CSV_COLUMN_PREFIXES.items()}
+        pop_idx = [col("population_" + band) for band in AGE_BANDS]
+        need = max([date_idx] + pop_idx + [i for v in idx.values() for i in v]) + 1
+        acc: Dict[str, list] = {k: [] for k in idx}
+        dates: List[str] = []
+        population = None
+        for raw in fh:
+            line = raw.rstrip("\r\n")
+            if line == "":
+                continue
+            row = line.split(",")
+            if line.endswith(","):
+                row.pop()
+            d = row[date_idx] if date_idx < len(row) else row[-1]
             if start_date and d < start_date:
                 continue
             if end_date and d > end_date:
                 continue
+            if len(row) < need:
+                raise fail  # "Insufficient columns in data row": readCSVData returns false
             dates.append(d)
-            for key, prefix in cols.items():
-                acc[key].append([float(row[prefix + band]) for band in AGE_BANDS])
-            if population is None:
-                population = np.array([float(row["population_" + band]) for band in AGE_BANDS])
+            try:
+                for key in idx:
+                    acc[key].append([float(row[i]) for i in idx[key]])
+                if population is None:
+                    population = np.array([float(row[i]) for i in pop_idx])
+            except ValueError as e:
+                raise RuntimeError("Failed to parse value: " + str(e)) from None
     if not dates:
-        raise ValueError("no data points in the requested date range")
+        raise fail
     return CalibrationData(dates=dates, population=population,
                            **{k: np.array(v, dtype=np.float64) for k, v in acc.items()})
 
@@ -155,9 +418,15 @@ def initial_sepaihrd_state(data: CalibrationData, sigma: float, gamma_p: float, 
     """CalibrationData::getInitialSEPAIHRDState (src/utils/GetCalibrationData.cpp:107-234).
 
     Heuristic 11n-vector anchored on the cumulative observations of day 0; it matters only
-    in the objective's *multiplier* branch (run-up disabled).
+    in the objective's *multiplier* branch (run-up disabled).  The reference's checks (:115-127) are runtime_errors.
     """
     n = len(data.population)
+    if data.num_data_points == 0:
+        raise RuntimeError("Cannot get initial SEPAIHRD state: No data points loaded.")
+    if len(p_asym) != n:
+        raise RuntimeError("p_asymptomatic vector size mismatch with num_age_classes.")
+    if len(h_hosp) != n:
+        raise RuntimeError("h_hospitalization vector size mismatch with num_age_classes.")
     N = data.population
     D0 = np.maximum(data.cumulative_deaths[0], 0.0)
     H0 = np.maximum(data.cumulative_hospitalizations[0], 0.0)
