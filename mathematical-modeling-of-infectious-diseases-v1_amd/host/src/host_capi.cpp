@@ -537,6 +537,10 @@ void host_glibc_exp(const double* x, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = sepaihrd_rng::glibc_exp(x[i]);
 }
 
+// SEPAIHRD_ARITH_* the reference-shaped constructors select (environment SEPAIHRD_ARITH): what bench.py's default --arith
+// must equal (tests/test_host_logic.py)
+int host_default_arith() { return HipSEPAIHRDObjectiveFunction::defaultArithmeticIsFma() ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT; }
+
 // Pure host (no GPU): exact-sort quantiles across chains of every column of a summary table, out [n_probs][width].
 int host_summary_quantiles(const double* table, int rows, int width, const double* probs, int n_probs, double* out) {
     try {

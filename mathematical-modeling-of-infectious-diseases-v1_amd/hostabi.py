@@ -389,6 +389,14 @@ def metropolis_hastings_group_summaries(objectives, initial, seed: int, iteratio
             "backend_used": int(used.value)}
 
 
+def default_arith() -> int:
+    """ARITH_* the reference-shaped constructors of the C++ adapters select (environment SEPAIHRD_ARITH; fma unless
+    "strict").  No device needed."""
+    lib = load_library()
+    lib.host_default_arith.restype = C.c_int
+    return int(lib.host_default_arith())
+
+
 def glibc_log(x) -> np.ndarray:
     """csrc/sepaihrd_rng.inc's restatement of glibc's log, compiled for the host (test hook)."""
     lib = load_library()

@@ -686,26 +686,38 @@ def test_scale_on_device_in_either_order_with_set_values(mm, shipped):
     assert np.array_equal(got[0], vals) and np.array_equal(got[1], vals)
 
 
-def test_reference_constructor_argument_lists(mm, shipped):
+def test_reference_constructor_argument_lists(mm, shipped, monkeypatch):
     """The drop-in at SEPAIHRDModelCalibration.cpp:84-118 is a change of two class names: the parameter manager and the
     objective are built with the reference's argument lists (shared_ptr<AgeSEPAIHRDModel> first,
     SEPAIHRDObjectiveFunction.hpp:49-58).  Same values as the struct-taking constructors in both constraint modes --
     with a HipSEPAIHRDParameterManager, and with an IParameterManager of another type whose mode is switched
     without telling the objective (what ModelCalibrator.cpp:62-64,88-90 does to the reference's own manager);
     updateModelParameters() writes into the model it was given."""
-    pb = shipped.with_(arith=mm.ARITH_STRICT)
     rs = np.random.RandomState(4)
-    lo, hi, _ = pb.bounds_arrays()
-    theta = lo + (hi - lo) * rs.uniform(-0.2, 1.2, (5, pb.n_params))   # beyond the bounds: the mode matters
-    theta[0] = pb.base_theta
+    lo, hi, _ = shipped.bounds_arrays()
+    theta = lo + (hi - lo) * rs.uniform(-0.2, 1.2, (5, shipped.n_params))   # beyond the bounds: the mode matters
+    theta[0] = shipped.base_theta
     theta[0, 3] = hi[3] + 0.3 * (hi[3] - lo[3])
-    got = mm.hostabi.reference_constructors(pb, theta)
-    for mode in (0, 1):
-        want, status = mm.HostObjective(pb.with_(constraint_mode=mode)).calculate_batch(theta)
-        assert np.all(status <= 1)
-        assert np.array_equal(got["values"][0, mode], want), mode
-        assert np.array_equal(got["values"][1, mode], want), mode
-    assert not np.array_equal(got["values"][0, 0], got["values"][0, 1])
+    # these constructors have no room for the arithmetic: fma (what bench.py's `value` is measured in) unless the
+    # environment says SEPAIHRD_ARITH=strict
+    by_arith = {}
+    for env, arith in ((None, mm.ARITH_FMA), ("strict", mm.ARITH_STRICT), ("fma", mm.ARITH_FMA)):
+        monkeypatch.delenv("SEPAIHRD_ARITH", raising=False)
+        if env:
+            monkeypatch.setenv("SEPAIHRD_ARITH", env)
+        assert mm.hostabi.default_arith() == arith
+        pb = shipped.with_(arith=arith)
+        got = mm.hostabi.reference_constructors(pb, theta)
+        for mode in (0, 1):
+            want, status = mm.HostObjective(pb.with_(constraint_mode=mode)).calculate_batch(theta)
+            assert np.all(status <= 1)
+            assert np.array_equal(got["values"][0, mode], want), (env, mode)
+            assert np.array_equal(got["values"][1, mode], want), (env, mode)
+        assert not np.array_equal(got["values"][0, 0], got["values"][0, 1])
+        by_arith[env] = got["values"].copy()
+    assert not np.array_equal(by_arith[None], by_arith["strict"]) and np.array_equal(by_arith[None], by_arith["fma"])
+    np.testing.assert_allclose(by_arith[None], by_arith["strict"], rtol=1e-7)
+    pb = shipped.with_(arith=mm.ARITH_STRICT)
     clamped = mm.HostObjective(pb, with_objective=False).apply_constraints(theta[0], 0)[0]
     assert np.array_equal(got["model_back"], clamped)
 

@@ -502,3 +502,33 @@ def test_every_declared_entry_point_has_a_ctypes_signature(mm):
     lib = mm.hipabi.load_library()
     missing = [n for n in names if getattr(lib, n).argtypes is None]
     assert not missing, missing
+
+
+def test_one_arithmetic_is_the_product_in_bench_adapter_and_docs(mm, monkeypatch):
+    """the arithmetic bench.py's `value` is measured in is the one the drop-in constructors select.
+    The choice is the measured one (profiles/r04_fma_vs_strict_100k.json: 4096 chains x 100 000 iterations, fma against
+    strict with the same seeds -- a flip would make strict the product): the committed verdict, bench.py's default
+    --arith, the C++ adapter's default and the documents must all say the same thing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04_fma_vs_strict_100k.json")) as fh:
+        run = json.load(fh)
+    assert run["chains"] == 4096 and run["iterations"] == 100000 and run["decisions_per_run"] == 4096 * 99999
+    assert run["verdict"] == ("strict" if run["chains_with_a_flip"] else "fma")
+    product = run["verdict"]
+    monkeypatch.delenv("SEPAIHRD_ARITH", raising=False)
+    assert mm.hostabi.default_arith() == {"fma": mm.ARITH_FMA, "strict": mm.ARITH_STRICT}[product]
+    monkeypatch.setenv("SEPAIHRD_ARITH", "strict")
+    assert mm.hostabi.default_arith() == mm.ARITH_STRICT          # the opt-in
+    monkeypatch.setenv("SEPAIHRD_ARITH", "fma")
+    assert mm.hostabi.default_arith() == mm.ARITH_FMA
+    # bench.py's parser default, read from the script itself (importing it is cheap: torch is only imported in main())
+    code = ("import sys; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench; print(bench.parse_args().arith)" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == product
+    for doc in ("README.md", "INTEGRATION.md"):
+        text = open(os.path.join(root, doc)).read()
+        assert "SEPAIHRD_ARITH=strict" in text, doc + " must name the opt-in"
+        assert "r04_fma_vs_strict_100k.json" in text, doc + " must cite the run that settled the arithmetic"
