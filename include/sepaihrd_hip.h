@@ -58,7 +58,10 @@ extern "C" {
  *    sepaihrd_mh_commit / _step is a bit field; sepaihrd_mh_create takes a struct sepaihrd_mh_config: ring of newest states,
  *    thinned samples and running co-moments instead of the whole chain history; sepaihrd_mh_read_samples /
  *    _sample_count / _summary_records / _read_moments added. */
-#define SEPAIHRD_ABI_VERSION 2
+/* 3: sepaihrd_kernel_info.phase_pass_applied; sepaihrd_device_libm_check (seed_streams / keep_scale_on_device refuse with
+ *    SEPAIHRD_E_UNSUPPORTED when the device's log / exp are not this host's libm); sepaihrd_mh_read_failure_counts;
+ *    sepaihrd_mh_snapshot_begin / _end (checkpoints without stalling the queue). */
+#define SEPAIHRD_ABI_VERSION 3
 #define SEPAIHRD_NUM_COMPARTMENTS 11 /* S,E,P,A,I,H,ICU,R,D,CumH,CumICU (ModelConstants.hpp:18) */
 #define SEPAIHRD_MAX_AGE_CLASSES 64  /* one lane per (chain, age class); 64/n chains per wavefront */
 #define SEPAIHRD_MAX_SCHEDULE 32     /* max beta / kappa periods */
@@ -391,6 +394,15 @@ int sepaihrd_mh_set_values(sepaihrd_mh *mh, const double *values);
  *                 moves by what the continuation taken used;
  *   draw_first    the normals of proposal 1 from the start of every stream, staged for sepaihrd_mh_step. */
 int sepaihrd_mh_seed_streams(sepaihrd_mh *mh, uint32_t seed0);
+/* The device's log and exp restate ONE libm build (glibc 2.35, x86-64, the FMA ifunc variants).  On a host with another
+ * glibc, or a CPU without FMA, the last bit may differ and device-drawn streams would silently stop being the host's.
+ * device_libm_check evaluates both device functions on 4096 fixed arguments (the sampler's own ranges, the near-1 branch of
+ * log, tiny arguments; log_scale_'s clamp range and beyond for exp) and compares them bit for bit with this process's
+ * std::log / std::exp: the counts of differing arguments (0 / 0 = safe), computed once per context.  seed_streams and
+ * keep_scale_on_device run it themselves and return SEPAIHRD_E_UNSUPPORTED on a difference; the C++ sampler then keeps
+ * draws and scale adaptation on the host (MultiChainMetropolisHastings::deviceStreamsFellBack()).
+ * Environment SEPAIHRD_LIBM_SELFCHECK=fail makes the check report a difference (test hook for that fall-back). */
+int sepaihrd_device_libm_check(sepaihrd_ctx *ctx, int32_t *n_log_diff, int32_t *n_exp_diff);
 int sepaihrd_mh_draw_first(sepaihrd_mh *mh);
 /* ... and the scalar scale adaptation: adaptGlobalScale (MetropolisHastingsSampler.cpp:104-152; log_scale_, the window of the
  * last 1000 accept flags, the emergency branches, global_scale_ = std::exp(log_scale_) with glibc's exp written out like its
@@ -406,6 +418,22 @@ int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh *mh, int adapt_scale, double ta
 int sepaihrd_mh_read_run_state(sepaihrd_mh *mh, double *values, double *best_values, double *scales, int32_t *accepted,
                                int32_t *emergency);
 int sepaihrd_mh_read_sample_values(sepaihrd_mh *mh, int first, int count, double *out);
+/* Progress reports and checkpoints WITHOUT draining the queue of a self-contained sampler.  The reference reports every
+ * report_interval iterations -- LogPost, Best, AccRate, Scale -- and rewrites posterior_trace_checkpoint.csv with the chain's
+ * last <= 5000 thinned samples (MetropolisHastingsSampler.cpp:363-383,440-469).
+ *   snapshot_begin  call it right behind the sepaihrd_mh_step_tested of the iteration to report: for the n listed chains a
+ *                   gather (on the sampler's stream: the values are that iteration's) of [value, best value, scale, accepted
+ *                   proposals] and of samples first_sample .. first_sample + count - 1 with their values, then the copy to the
+ *                   host on a stream of its own.  Returns at once; the run goes on.  One snapshot in flight at a time.
+ *   snapshot_end    wait != 0: blocks until it has landed; wait == 0: returns 1 while it has not.  0: state [n][4],
+ *                   samples [n][count][P], sample_values [n][count] are filled (any may be NULL).  May be called from another
+ *                   host thread than the one that queues the iterations. */
+int sepaihrd_mh_snapshot_begin(sepaihrd_mh *mh, const int32_t *chains, int n, int first_sample, int count);
+int sepaihrd_mh_snapshot_end(sepaihrd_mh *mh, int wait, double *state, double *samples, double *sample_values);
+/* evaluations the accept test saw FAIL, whole sampler: counts[0] status 2 (500 rejections), [1] status 3 (attempt budget),
+ * [2] status 4 (SEPAIHRD_STATUS_PIPELINE).  They enter the test as -1e18 like a throwing objective and would otherwise look
+ * like ordinary rejections; a non-zero PIPELINE count is a defect of this build, not of the model. */
+int sepaihrd_mh_read_failure_counts(sepaihrd_mh *mh, int64_t counts[3]);
 int sepaihrd_mh_read_accept_trace(sepaihrd_mh *mh, uint8_t *out);
 double *sepaihrd_mh_test_buffer(sepaihrd_mh *mh);
 int sepaihrd_mh_step_tested(sepaihrd_mh *mh, double gamma, int adapt, int last);
@@ -466,6 +494,9 @@ typedef struct sepaihrd_kernel_info {
     int32_t max_blocks_per_cu; /* occupancy query */
     int32_t num_cus;
     int32_t likelihood_form;   /* SEPAIHRD_LL_*: where the Poisson terms of such a launch are evaluated */
+    int32_t phase_pass_applied; /* 1: the kernel's code went through csrc/phase_pass.py at build time (the instruction-fetch
+                                   phase of its RK body is set; worth 1-3 %); 0: the build fell back to the plain compile,
+                                   or the kernel (fp32 state) does not use the pass */
     char kernel_name[128];
     char device_name[128];
 } sepaihrd_kernel_info;

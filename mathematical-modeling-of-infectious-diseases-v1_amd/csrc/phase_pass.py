@@ -10,11 +10,17 @@ inside a stage.  This pass walks the big straight-line blocks of the chosen kern
 block as its 8-byte VOP3 form (`_e32` -> `_e64`: the same instruction, no issue slot, four more bytes), or -- if there is none
 close enough -- inserts one `s_nop 0` when the run is long enough to pay for it.
 
-usage: phase_pass.py <in.s> <out.s> [--arith fma|strict] [--kernels substr,substr] [--min-run N]
-Needs the assembler of the image (addresses come from assembling the input once)."""
+usage: phase_pass.py <in.s> <out.s> [--kernels substr,substr] [--min-run N] [--llvm DIR] [--mcpu ARCH]
+Needs the assembler of the image: addresses come from assembling the input once, and the OUTPUT is assembled again at the end --
+the phases the pass reports are read off that second object, not off its own bookkeeping (alignment padding inside a function
+moves code in ways the running byte count does not see); an output that does not assemble is an error (exit status 1).
+
+Never touched: the instructions from an `s_getpc_b64` to the last `@rel32` operand behind it.  Their literals encode distances
+from the `s_getpc_b64` (`sym@rel32@lo+4`, `@hi+12`): a pad or a wider encoding BETWEEN them would silently corrupt the address."""
 import argparse, os, re, subprocess, sys, tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+LLVM = "/opt/rocm/lib/llvm/bin"   # --llvm overrides (csrc/Makefile passes its $(LLVM))
+MCPU = "gfx950"                   # --mcpu overrides (csrc/Makefile passes its $(ARCH))
 E64_OK = re.compile(r"^\s+(v_fmac_f64_e32|v_mov_b32_e32|v_mov_b64_e32|v_add_u32_e32|v_sub_u32_e32|v_subrev_u32_e32|v_mul_f32_e32|v_add_f32_e32|"
                     r"v_cvt_f32_f64_e32|v_cvt_f64_f32_e32|v_cvt_f64_i32_e32|v_rcp_f64_e32|v_log_f32_e32|v_exp_f32_e32|v_and_b32_e32|v_or_b32_e32|"
                     r"v_lshlrev_b32_e32|v_max_i32_e32|v_min_i32_e32)\b")
@@ -24,7 +30,7 @@ def assemble_sizes(path):
     """[(function, [sizes of its instructions in order])] from assembling `path`"""
     tmp = tempfile.mkdtemp(prefix="pp_")
     obj = os.path.join(tmp, "a.o")
-    subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", path, "-o", obj], check=True,
+    subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + MCPU, "-c", path, "-o", obj], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dis = subprocess.run([LLVM + "/llvm-objdump", "-d", obj], check=True, capture_output=True, text=True).stdout
     out, cur = {}, None
@@ -39,12 +45,58 @@ def assemble_sizes(path):
     return out
 
 
+def protected_spans(lines, idxs):
+    """Positions (indices into idxs) that lie strictly behind an s_getpc_b64 and up to the last instruction within reach that
+    names an @rel32 operand: nothing may be inserted in front of them or re-encoded among them."""
+    out = set()
+    for k, li in enumerate(idxs):
+        if not lines[li].strip().startswith("s_getpc_b64"):
+            continue
+        last = k
+        for m in range(k + 1, min(k + 8, len(idxs))):
+            if "@rel32" in lines[idxs[m]]:
+                last = m
+        out.update(range(k + 1, last + 1))
+    return out
+
+
+def off_phase_runs(sizes, wanted, min_run, min_block):
+    """(runs of >= min_run wide encodings inside the big straight-line blocks of the wanted kernels, those that start 4 bytes
+    off an 8-byte boundary) -- read off an assembled object's real addresses"""
+    n_runs = n_off = 0
+    for name, ins in sizes.items():
+        if not any(w in name for w in wanted):
+            continue
+        start = 0
+        for k in range(len(ins) + 1):
+            if not (k == len(ins) or ins[k][2].startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc"))):
+                continue
+            blk = ins[start:min(k + 1, len(ins))]
+            start = k + 1
+            if len(blk) < min_block:
+                continue
+            j = 0
+            while j < len(blk):
+                if blk[j][1] != 8:
+                    j += 1
+                    continue
+                r = j
+                while r < len(blk) and blk[r][1] == 8:
+                    r += 1
+                if r - j >= min_run:
+                    n_runs += 1
+                    n_off += blk[j][0] % 8 == 4
+                j = r
+    return n_runs, n_off
+
+
 def is_instruction(line):
     t = line.strip()
     return bool(t) and not t.startswith((";", ".", "//", "#")) and not re.match(r"^[\w.$]+:", t)
 
 
 def main():
+    global LLVM, MCPU
     ap = argparse.ArgumentParser()
     ap.add_argument("src"); ap.add_argument("dst")
     ap.add_argument("--kernels", default="sepaihrd_eval_quad_kernel,sepaihrd_eval_kernelILi16E")
@@ -52,7 +104,10 @@ def main():
     ap.add_argument("--min-block", type=int, default=200)
     ap.add_argument("--nop-run", type=int, default=7, help="insert s_nop 0 in front of an off-phase run at least this long when nothing can be re-encoded")
     ap.add_argument("--look-back", type=int, default=12)
+    ap.add_argument("--llvm", default=LLVM, help="directory of clang / llvm-objdump")
+    ap.add_argument("--mcpu", default=MCPU)
     args = ap.parse_args()
+    LLVM, MCPU = args.llvm, args.mcpu
     wanted = args.kernels.split(",")
     sizes = assemble_sizes(args.src)
     lines = open(args.src).read().split("\n")
@@ -77,6 +132,7 @@ def main():
         if len(ins) != len(idxs):
             print(f"skip {name[:70]}: {len(ins)} disassembled vs {len(idxs)} listed instructions", file=sys.stderr)
             continue
+        guarded = protected_spans(lines, idxs)
         # straight-line blocks
         start = 0
         shift = 0  # bytes added in this function so far: every edit moves everything behind it
@@ -105,12 +161,16 @@ def main():
                         fixed = False
                         for b in range(j - 1, max(j - 1 - args.look_back, last_touch), -1):
                             li = idxs[blk[b]]
+                            # a wider encoding INSIDE an s_getpc_b64 .. @rel32 span would move the literal's reference point;
+                            # in front of the s_getpc_b64 it moves both alike
+                            if blk[b] in guarded:
+                                continue
                             if ins[blk[b]][1] == 4 and li not in edits and E64_OK.match(lines[li]) and "0x" not in lines[li] and "dpp" not in lines[li] and "sdwa" not in lines[li]:
                                 # what lies between it and the run is 4-byte stuff and short runs: their phase flips too, accepted
                                 edits[li] = lines[li].replace("_e32", "_e64", 1)
                                 shift += 4; n_re += 1; fixed = True; last_touch = b
                                 break
-                        if not fixed and run_len >= args.nop_run:
+                        if not fixed and run_len >= args.nop_run and a not in guarded:
                             inserts[idxs[a]] = "\ts_nop 0"
                             shift += 4; n_nop += 1; fixed = True; last_touch = j
                         n_fixed += fixed
@@ -121,7 +181,19 @@ def main():
             out.append(inserts[i])
         out.append(edits.get(i, l))
     open(args.dst, "w").write("\n".join(out))
-    print(f"runs of >= {args.min_run} wide encodings: {n_runs}; off phase and fixed: {n_fixed} ({n_re} re-encoded, {n_nop} s_nop)")
+    # the output's phases from ITS OWN addresses (the byte count kept above does not see alignment padding inside a function)
+    try:
+        after = assemble_sizes(args.dst)
+    except subprocess.CalledProcessError:
+        print("phase_pass: the rewritten assembly does not assemble", file=sys.stderr)
+        sys.exit(1)
+    runs_before, off_before = off_phase_runs(sizes, wanted, args.min_run, args.min_block)
+    runs_after, off_after = off_phase_runs(after, wanted, args.min_run, args.min_block)
+    print(f"runs of >= {args.min_run} wide encodings: {n_runs}; off phase and fixed: {n_fixed} ({n_re} re-encoded, {n_nop} s_nop); "
+          f"off-phase runs by the assembled addresses: {off_before} of {runs_before} before, {off_after} of {runs_after} after")
+    if off_after > off_before:
+        print("phase_pass: the rewritten assembly has MORE off-phase runs than its input", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

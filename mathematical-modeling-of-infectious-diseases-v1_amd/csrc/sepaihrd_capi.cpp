@@ -69,6 +69,9 @@ struct sepaihrd_ctx {
     // kernels of a stream is dispatch latency (3-5 us each in the sampler loop).  The event is re-recorded lazily when
     // another stream asks (fence_before); only for an owned stream, whose handle is known to be alive
     hipStream_t lazy_stream = nullptr;
+    // sepaihrd_device_libm_check: -1 not run yet, else the number of self-check arguments on which the device's log / exp
+    // restatements differ from this process's libm
+    int libm_log_diff = -1, libm_exp_diff = -1;
     // optional per-kernel timing (HIP events on the launch stream), see sepaihrd_set_timing
     bool timing = false;
     int timing_period = 1;     // events around every timing_period-th launch sequence only
@@ -875,6 +878,9 @@ int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx* ctx, int32_t batch_chains, 
     info->lds_bytes = li.lds_static + (int)eval_lds_bytes(ctx->dp);
     info->max_blocks_per_cu = li.max_blocks_per_cu;
     info->likelihood_form = li.likelihood_form;
+    info->phase_pass_applied = ctx->precision == SEPAIHRD_PRECISION_F32 ? 0  // the fp32-state kernel does not go through the pass
+                               : ctx->arith == SEPAIHRD_ARITH_FMA       ? phase_pass_applied_fma()
+                                                                        : phase_pass_applied_strict();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device), ctx, return SEPAIHRD_E_HIP);
     info->num_cus = prop.multiProcessorCount;
@@ -946,6 +952,16 @@ struct sepaihrd_mh {
     int covariance_mode = SEPAIHRD_MH_COV_RUNNING;
     int iterations = 0;
     double* d_summary = nullptr;
+    // sepaihrd_mh_snapshot_begin / _end: a gather on the sampler's stream, the copy home on a stream of its own
+    hipStream_t snap_stream = nullptr;
+    hipEvent_t ev_snap_gathered = nullptr, ev_snap_done = nullptr;
+    double* d_snap = nullptr;
+    double* h_snap = nullptr;   // page-locked
+    int32_t* d_snap_chains = nullptr;
+    size_t snap_cap = 0, snap_chain_cap = 0;
+    int snap_n = 0, snap_count = 0;
+    bool snap_pending = false;
+    std::vector<int32_t> snap_chain_list;  // what d_snap_chains holds
     std::vector<void*> allocs;
 };
 
@@ -1104,6 +1120,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     dalloc((void**)&st.wmean, CP * sizeof(double));
     dalloc((void**)&st.m2, CPP * sizeof(double));
     dalloc((void**)&st.accepted, (size_t)C * sizeof(int32_t));
+    dalloc((void**)&st.fail_counts, 3 * sizeof(uint32_t));
     dalloc((void**)&st.mt, (size_t)C * 624 * sizeof(uint32_t));
     dalloc((void**)&st.mt_idx, (size_t)C * sizeof(int32_t));
     dalloc((void**)&st.mt_used, (size_t)C * 2 * sizeof(int32_t));
@@ -1143,7 +1160,8 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     if (ok) ok = hipMemsetAsync(st.sum, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
                  hipMemsetAsync(st.wmean, 0, CP * sizeof(double), mh->stream) == hipSuccess &&
                  hipMemsetAsync(st.m2, 0, CPP * sizeof(double), mh->stream) == hipSuccess &&
-                 hipMemsetAsync(st.accepted, 0, (size_t)C * sizeof(int32_t), mh->stream) == hipSuccess;
+                 hipMemsetAsync(st.accepted, 0, (size_t)C * sizeof(int32_t), mh->stream) == hipSuccess &&
+                 hipMemsetAsync(st.fail_counts, 0, 3 * sizeof(uint32_t), mh->stream) == hipSuccess;
     if (ok) {
         std::vector<double> cov_all(CPP);
         for (int c = 0; c < C; ++c) std::copy(cov0, cov0 + (size_t)P * P, cov_all.begin() + (size_t)c * P * P);
@@ -1195,6 +1213,11 @@ void sepaihrd_mh_destroy(sepaihrd_mh* mh) {
     if (mh->h_test_out) (void)hipHostFree(mh->h_test_out);
     for (double* b : mh->h_stage) if (b) (void)hipHostFree(b);
     for (void* p : mh->allocs) (void)hipFree(p);
+    if (mh->snap_stream) { (void)hipStreamSynchronize(mh->snap_stream); (void)hipStreamDestroy(mh->snap_stream); }
+    for (hipEvent_t e : {mh->ev_snap_gathered, mh->ev_snap_done}) if (e) (void)hipEventDestroy(e);
+    if (mh->d_snap) (void)hipFree(mh->d_snap);
+    if (mh->h_snap) (void)hipHostFree(mh->h_snap);
+    if (mh->d_snap_chains) (void)hipFree(mh->d_snap_chains);
     if (mh->d_rows) (void)hipFree(mh->d_rows);
     if (mh->d_gather) (void)hipFree(mh->d_gather);
     if (mh->d_r1) (void)hipFree(mh->d_r1);
@@ -1307,10 +1330,62 @@ int sepaihrd_mh_set_values(sepaihrd_mh* mh, const double* values) {
 
 double* sepaihrd_mh_test_buffer(sepaihrd_mh* mh) { return mh ? mh->h_test : nullptr; }
 
+// The device's log / exp (csrc/sepaihrd_rng.inc) restate ONE libm build.  Before a sampler lets the device draw, they are
+// evaluated on fixed arguments and compared, bit for bit, with the std::log / std::exp of THIS process.
+int sepaihrd_device_libm_check(sepaihrd_ctx* ctx, int32_t* n_log_diff, int32_t* n_exp_diff) {
+    if (!ctx) return SEPAIHRD_E_INVALID_ARG;
+    if (ctx->libm_log_diff < 0) {
+        HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+        const int N = sampler_libm_check_count();
+        double* d_out = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_out, 4 * (size_t)N * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        std::vector<double> h(4 * (size_t)N);
+        const bool ok = sampler_libm_check_values(d_out, nullptr) == 0 &&
+                        hipMemcpy(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d_out);
+        if (!ok) { ctx->last_error = "device_libm_check: launch or copy failed"; return SEPAIHRD_E_HIP; }
+        int dl = 0, de = 0;
+        for (int i = 0; i < N; ++i) {
+            // volatile: the comparison must be against the library call, not against a constant the compiler folded
+            volatile double xl = h[(size_t)i], xe = h[2 * (size_t)N + i];
+            const double hl = std::log(xl), he = std::exp(xe);
+            if (std::memcmp(&hl, &h[(size_t)N + i], sizeof(double)) != 0) ++dl;
+            if (std::memcmp(&he, &h[3 * (size_t)N + i], sizeof(double)) != 0) ++de;
+        }
+        // test hook: pretend this host's libm is another one (the fall-back to host-drawn streams is then exercised on a
+        // box whose libm does match)
+        if (const char* e = std::getenv("SEPAIHRD_LIBM_SELFCHECK")) if (std::string(e) == "fail") { dl += 1; de += 1; }
+        ctx->libm_log_diff = dl;
+        ctx->libm_exp_diff = de;
+    }
+    if (n_log_diff) *n_log_diff = ctx->libm_log_diff;
+    if (n_exp_diff) *n_exp_diff = ctx->libm_exp_diff;
+    return SEPAIHRD_OK;
+}
+
+namespace {
+// seed_streams / keep_scale_on_device refuse when the device functions are not this host's libm
+int mh_require_matching_libm(sepaihrd_mh* mh, const char* who) {
+    sepaihrd_ctx* ctx = mh->ctx;
+    int32_t dl = 0, de = 0;
+    const int rc = sepaihrd_device_libm_check(ctx, &dl, &de);
+    if (rc != SEPAIHRD_OK) return rc;
+    if (dl == 0 && de == 0) return SEPAIHRD_OK;
+    char msg[384];
+    std::snprintf(msg, sizeof(msg),
+                  "%s: the device's log / exp (csrc/sepaihrd_rng.inc: glibc 2.35, x86-64, FMA variants) differ from this host's libm on %d "
+                  "(log) and %d (exp) of %d self-check arguments: streams drawn on the device would not be the host's -- keep the draws "
+                  "and the scale adaptation on the host (device_streams 0)", who, dl, de, sampler_libm_check_count());
+    ctx->last_error = msg;
+    return SEPAIHRD_E_UNSUPPORTED;
+}
+}  // namespace
+
 int sepaihrd_mh_seed_streams(sepaihrd_mh* mh, uint32_t seed0) {
     if (!mh) return SEPAIHRD_E_INVALID_ARG;
     sepaihrd_ctx* ctx = mh->ctx;
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (const int rc = mh_require_matching_libm(mh, "mh_seed_streams")) return rc;
     if (sampler_seed_streams(mh->st, seed0, mh->stream) != 0) { ctx->last_error = "mh_seed_streams: launch failed"; return SEPAIHRD_E_HIP; }
     HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
     mh->device_rng = true;
@@ -1325,8 +1400,23 @@ int sepaihrd_mh_keep_scale_on_device(sepaihrd_mh* mh, int adapt_scale, double ta
         ctx->last_error = "mh_keep_scale_on_device: call it before the first iteration (the accept window and the sample values start with the run)";
         return SEPAIHRD_E_INVALID_ARG;
     }
+    if (adapt_scale)  // global_scale_ = exp(log_scale_) on the device
+        if (const int rc = mh_require_matching_libm(mh, "mh_keep_scale_on_device")) return rc;
     SamplerState& st = mh->st;
     const size_t C = (size_t)st.C;
+    {   // what this call adds to the sampler's state (sepaihrd_mh_create budgeted the rest): say so before failing inside
+        const double need = (double)C * (1000.0 + 16.0 + 16.0) + (st.n_store > 0 && !st.lp_store ? (double)C * st.n_store * 8.0 : 0.0) +
+                            (keep_trace && mh->iterations > 1 && !st.trace ? (double)C * (double)(mh->iterations - 1) : 0.0);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) {
+            char msg[256];
+            std::snprintf(msg, sizeof(msg), "mh_keep_scale_on_device: the accept window, the sample values and %s need %.3f GB but %.3f GB "
+                          "of device memory are free", keep_trace ? "the accept trace (C * (iterations - 1) bytes)" : "no trace",
+                          need / 1e9, (double)free_b / 1e9);
+            ctx->last_error = msg;
+            return SEPAIHRD_E_HIP;
+        }
+    }
     auto dalloc = [&](void** p, size_t bytes) -> bool {
         if (*p) return true;
         if (hipMalloc(p, bytes) != hipSuccess) return false;
@@ -1371,6 +1461,94 @@ int sepaihrd_mh_read_run_state(sepaihrd_mh* mh, double* values, double* best_val
         HIP_TRY(hipMemcpy2D(emergency, sizeof(int32_t), mh->st.recent_meta + 3, 4 * sizeof(int32_t), sizeof(int32_t), C, hipMemcpyDeviceToHost), ctx,
                 return SEPAIHRD_E_HIP);
     }
+    return SEPAIHRD_OK;
+}
+
+// Progress reports and checkpoints of a run whose iterations are queued ahead (MetropolisHastingsSampler.cpp:363-383 reads the
+// chain's value, best value, acceptance count, scale and -- for posterior_trace_checkpoint.csv -- its newest samples every
+// report_interval iterations).  Reading them with the synchronous getters would drain the queue.
+int sepaihrd_mh_snapshot_begin(sepaihrd_mh* mh, const int32_t* chains, int n, int first_sample, int count) {
+    if (!mh || !chains || n <= 0 || first_sample < 0 || count < 0) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    const int C = mh->st.C, P = mh->st.P;
+    if (mh->snap_pending) { ctx->last_error = "mh_snapshot_begin: the previous snapshot has not been collected (sepaihrd_mh_snapshot_end)"; return SEPAIHRD_E_INVALID_ARG; }
+    if (!mh->values_set) { ctx->last_error = "mh_snapshot_begin: the chains' values are unknown (sepaihrd_mh_set_values)"; return SEPAIHRD_E_INVALID_ARG; }
+    if (count > 0 && first_sample + count > sepaihrd_mh_sample_count(mh)) { ctx->last_error = "mh_snapshot_begin: beyond the samples stored so far"; return SEPAIHRD_E_INVALID_ARG; }
+    for (int k = 0; k < n; ++k)
+        if (chains[k] < 0 || chains[k] >= C) { ctx->last_error = "mh_snapshot_begin: chain out of range"; return SEPAIHRD_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    if (!mh->snap_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&mh->snap_stream, hipStreamNonBlocking), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventCreateWithFlags(&mh->ev_snap_gathered, hipEventDisableTiming), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipEventCreateWithFlags(&mh->ev_snap_done, hipEventDisableTiming), ctx, return SEPAIHRD_E_HIP);
+    }
+    const size_t width = 4 + (size_t)count * ((size_t)P + 1), need = (size_t)n * width;
+    if (need > mh->snap_cap) {  // the previous snapshot has been collected: nothing reads the old buffers any more
+        if (mh->d_snap) (void)hipFree(mh->d_snap);
+        if (mh->h_snap) (void)hipHostFree(mh->h_snap);
+        mh->d_snap = mh->h_snap = nullptr;
+        mh->snap_cap = 0;
+        HIP_TRY(hipMalloc((void**)&mh->d_snap, need * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+        HIP_TRY(hipHostMalloc((void**)&mh->h_snap, need * sizeof(double), hipHostMallocDefault), ctx, return SEPAIHRD_E_HIP);
+        mh->snap_cap = need;
+    }
+    if ((size_t)n > mh->snap_chain_cap) {
+        if (mh->d_snap_chains) (void)hipFree(mh->d_snap_chains);
+        mh->d_snap_chains = nullptr;
+        mh->snap_chain_cap = 0;
+        mh->snap_chain_list.clear();
+        HIP_TRY(hipMalloc((void**)&mh->d_snap_chains, (size_t)n * sizeof(int32_t)), ctx, return SEPAIHRD_E_HIP);
+        mh->snap_chain_cap = (size_t)n;
+    }
+    // the chain list is uploaded when it changes (every report of a run names the same chains): a blocking copy once, none after
+    if (mh->snap_chain_list.size() != (size_t)n || !std::equal(chains, chains + n, mh->snap_chain_list.begin())) {
+        HIP_TRY(hipMemcpy(mh->d_snap_chains, chains, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice), ctx, return SEPAIHRD_E_HIP);
+        mh->snap_chain_list.assign(chains, chains + n);
+    }
+    if (sampler_snapshot(mh->st, mh->d_lp, mh->d_best_lp, mh->d_snap_chains, n, first_sample, count, mh->d_snap, mh->stream) != 0) {
+        ctx->last_error = "mh_snapshot_begin: launch failed";
+        return SEPAIHRD_E_HIP;
+    }
+    HIP_TRY(hipEventRecord(mh->ev_snap_gathered, mh->stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamWaitEvent(mh->snap_stream, mh->ev_snap_gathered, 0), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipMemcpyAsync(mh->h_snap, mh->d_snap, need * sizeof(double), hipMemcpyDeviceToHost, mh->snap_stream), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipEventRecord(mh->ev_snap_done, mh->snap_stream), ctx, return SEPAIHRD_E_HIP);
+    mh->snap_n = n;
+    mh->snap_count = count;
+    mh->snap_pending = true;
+    return SEPAIHRD_OK;
+}
+
+// returns 1 while the snapshot has not landed (wait == 0 only), 0 with the outputs filled, < 0 on error.  May be called from
+// another host thread than the one that queues the iterations (it touches the snapshot's own event and buffer only).
+int sepaihrd_mh_snapshot_end(sepaihrd_mh* mh, int wait, double* state, double* samples, double* sample_values) {
+    if (!mh) return SEPAIHRD_E_INVALID_ARG;
+    if (!mh->snap_pending) return SEPAIHRD_E_INVALID_ARG;
+    if (hipSetDevice(mh->ctx->device) != hipSuccess) return SEPAIHRD_E_HIP;
+    if (!wait) {
+        const hipError_t q = hipEventQuery(mh->ev_snap_done);
+        if (q == hipErrorNotReady) return 1;
+        if (q != hipSuccess) return SEPAIHRD_E_HIP;
+    } else if (hipEventSynchronize(mh->ev_snap_done) != hipSuccess) return SEPAIHRD_E_HIP;
+    const size_t P = (size_t)mh->st.P, count = (size_t)mh->snap_count, width = 4 + count * (P + 1);
+    for (int k = 0; k < mh->snap_n; ++k) {
+        const double* o = mh->h_snap + (size_t)k * width;
+        if (state) std::memcpy(state + 4 * (size_t)k, o, 4 * sizeof(double));
+        if (samples && count) std::memcpy(samples + (size_t)k * count * P, o + 4, count * P * sizeof(double));
+        if (sample_values && count) std::memcpy(sample_values + (size_t)k * count, o + 4 + count * P, count * sizeof(double));
+    }
+    mh->snap_pending = false;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_mh_read_failure_counts(sepaihrd_mh* mh, int64_t counts[3]) {
+    if (!mh || !counts) return SEPAIHRD_E_INVALID_ARG;
+    sepaihrd_ctx* ctx = mh->ctx;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    HIP_TRY(hipStreamSynchronize(mh->stream), ctx, return SEPAIHRD_E_HIP);
+    uint32_t h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h, mh->st.fail_counts, sizeof(h), hipMemcpyDeviceToHost), ctx, return SEPAIHRD_E_HIP);
+    for (int k = 0; k < 3; ++k) counts[k] = (int64_t)h[k];
     return SEPAIHRD_OK;
 }
 

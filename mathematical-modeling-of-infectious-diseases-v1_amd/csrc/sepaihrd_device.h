@@ -99,6 +99,9 @@ int kernel_info_f32(const DevProblem& pb, int solver, LaunchInfo* info);
 // batch <= 0: the large-batch kernel
 int kernel_info_strict(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
 int kernel_info_fma(const DevProblem& pb, int solver, int batch, LaunchInfo* info);
+// 1 when the translation unit's device code went through csrc/phase_pass.py (csrc/Makefile), 0 for the plain compile
+int phase_pass_applied_strict();
+int phase_pass_applied_fma();
 
 // ---- posterior ensemble summaries (csrc/sepaihrd_ensemble.hip) ----
 constexpr int ENSEMBLE_MAX_SAMPLES = 16384;  // one sorted segment lives in LDS (128 KiB of 160 KiB)
@@ -199,7 +202,15 @@ struct SamplerState {
     int32_t* recent_meta;   // [C][4]: position, length, sum, emergency shrinks
     double* lp_store;       // [C][n_store] the chain's value at every stored sample (sampleObjectiveValues)
     uint8_t* trace;         // [iterations - 1][C] accept flags of every test, or null
+    uint32_t* fail_counts;  // [3] evaluations the accept test saw with status 2, 3, 4 (whole sampler), or null
 };
+// the device's glibc_log / glibc_exp on the N = sampler_libm_check_count() self-check arguments of csrc/sepaihrd_rng.inc:
+// d_out [log args N | log values N | exp args N | exp values N]
+int sampler_libm_check_values(double* d_out, void* stream);
+int sampler_libm_check_count();
+// progress / checkpoint block of n chains: per chain [value, best, scale, accepted | samples first.. [count][P] | values [count]]
+int sampler_snapshot(const SamplerState& s, const double* d_lp, const double* d_best_lp, const int32_t* d_chains, int n, int first,
+                     int count, double* d_out, void* stream);
 int sampler_propose(const SamplerState& s, const DevProblem& pb, const double* d_z, const double* d_scale, void* stream);
 int sampler_commit(const SamplerState& s, const uint8_t* d_accept, int row, void* stream);
 int sampler_commit_counted(const SamplerState& s, const uint8_t* d_accept, int row, int accepted_known, void* stream);

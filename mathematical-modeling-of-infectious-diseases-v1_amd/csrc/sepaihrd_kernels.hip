@@ -1277,11 +1277,13 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
 #define SEP_LAUNCH launch_eval_fma
 #define SEP_NEEDS_WS launch_needs_workspace_fma
 #define SEP_INFO kernel_info_fma
+#define SEP_PHASED phase_pass_applied_fma
 #define SEP_NAME "sepaihrd_eval_kernel[fma]"
 #else
 #define SEP_LAUNCH launch_eval_strict
 #define SEP_NEEDS_WS launch_needs_workspace_strict
 #define SEP_INFO kernel_info_strict
+#define SEP_PHASED phase_pass_applied_strict
 #define SEP_NAME "sepaihrd_eval_kernel[strict]"
 #endif
 
@@ -1295,5 +1297,11 @@ int SEP_NEEDS_WS(const DevProblem& pb, int solver, int B, int force_split) {
 int SEP_INFO(const DevProblem& pb, int solver, int batch, LaunchInfo* info) {
     SEP_DISPATCH(info_one, pb, batch, info, SEP_NAME)
 }
+// csrc/Makefile compiles the host half of this file with -DSEPAIHRD_PHASE_PASS_APPLIED=1 when the device half it embeds came
+// out of csrc/phase_pass.py, and with =0 when that step failed and the plain compile was used
+#ifndef SEPAIHRD_PHASE_PASS_APPLIED
+#define SEPAIHRD_PHASE_PASS_APPLIED 0
+#endif
+int SEP_PHASED() { return SEPAIHRD_PHASE_PASS_APPLIED; }
 
 }  // namespace sepaihrd

@@ -161,6 +161,12 @@ __device__ __forceinline__ double adapt_global_scale(const SamplerState& s, cons
     s.scale[c] = sc;
     return sc;
 }
+// An evaluation that FAILED (status 2 odeint's 500 rejections, 3 the attempt budget, 4 the hand-off guard between an
+// integrating wave and its likelihood wave) enters the accept test as -1e18 like a throwing objective (safeEvaluate :65-74) and
+// would otherwise be indistinguishable from an ordinary rejection: counted here, read with sepaihrd_mh_read_failure_counts.
+__device__ __forceinline__ void count_failure(const SamplerState& s, const int32_t st) {
+    if (st >= 2 && s.fail_counts != nullptr) atomicAdd(&s.fail_counts[(st > 4 ? 4 : st) - 2], 1u);
+}
 // what else the device keeps of a test's outcome: the value of every stored sample and the accept trace
 __device__ __forceinline__ void record_outcome(const SamplerState& s, const int c, const int row, const bool accepted, const double lp_now) {
     if (s.lp_store != nullptr && s.n_store > 0 && row % s.thinning == 0 && row / s.thinning < s.n_store)
@@ -184,6 +190,7 @@ __global__ void mh_accept_kernel(const SamplerState s, const int row, const doub
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double v = loglik[c];
+    count_failure(s, status[c]);
     if (status[c] >= 2 || isnan(v) || isinf(v)) v = -1e18;
     const double log_ratio = v - lp[c];
     const bool no_uniform = log_ratio >= 0.0;
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(2 * WAVE) void mh_test_commit_propose_kernel(const 
         }
         if (lane == 0) {
             double v = loglik[c];
+            count_failure(s, status[c]);
             if (status[c] >= 2 || isnan(v) || isinf(v)) v = -1e18;
             const double log_ratio = v - lp[c];
             const bool no_uniform = log_ratio >= 0.0;
@@ -489,6 +497,28 @@ __global__ void mh_summary_kernel(const SamplerState s, const double* __restrict
         out[(size_t)c * W + 2 * s.P] = best_lp[c];
         out[(size_t)c * W + 2 * s.P + 1] = (double)s.accepted[c];
     }
+}
+
+// What a progress report / checkpoint of the run reads (MetropolisHastingsSampler.cpp:363-383,440-469), for the n listed chains,
+// gathered into one contiguous block so that it can leave the device on another stream while the run goes on:
+//   out[k] = [value, best value, scale, accepted | samples first .. first + count - 1, [count][P] | their values [count]]
+// Launched on the sampler's own stream right behind the iteration it reports: the values are that iteration's.
+__global__ void mh_snapshot_kernel(const SamplerState s, const double* __restrict__ lp, const double* __restrict__ best_lp,
+                                   const int32_t* __restrict__ chains, const int first, const int count, double* out) {
+    const int k = blockIdx.x;
+    const int c = chains[k];
+    const size_t width = 4 + (size_t)count * ((size_t)s.P + 1);
+    double* const o = out + (size_t)k * width;
+    if (threadIdx.x == 0) {
+        o[0] = lp[c];
+        o[1] = best_lp[c];
+        o[2] = s.scale != nullptr ? s.scale[c] : 1.0;
+        o[3] = (double)s.accepted[c];
+    }
+    const double* src = s.store + ((size_t)c * s.n_store + first) * s.P;
+    for (size_t i = threadIdx.x; i < (size_t)count * s.P; i += blockDim.x) o[4 + i] = src[i];
+    if (s.lp_store != nullptr)
+        for (int i = threadIdx.x; i < count; i += blockDim.x) o[4 + (size_t)count * s.P + i] = s.lp_store[(size_t)c * s.n_store + first + i];
 }
 
 // pass 1 of recomputeFullCovariance: mean_i = (sum_s h[s][i]) / len, s ascending
@@ -737,6 +767,24 @@ __global__ __launch_bounds__(WAVE) void mh_draw_kernel(const SamplerState s, con
 
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// the device's log / exp on the self-check arguments of csrc/sepaihrd_rng.inc; the arguments go back with the values so that
+// the host compares on exactly the doubles the device used.  out: [log args N | log values N | exp args N | exp values N]
+__global__ void libm_check_kernel(double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int N = sepaihrd_rng::LIBM_CHECK_N;
+    if (i >= N) return;
+    const double xl = sepaihrd_rng::libm_check_log_arg(i), xe = sepaihrd_rng::libm_check_exp_arg(i);
+    out[i] = xl;
+    out[N + i] = sepaihrd_rng::glibc_log(xl);
+    out[2 * N + i] = xe;
+    out[3 * N + i] = sepaihrd_rng::glibc_exp(xe);
+}
+int sampler_libm_check_values(double* d_out, void* stream) {
+    hipLaunchKernelGGL(libm_check_kernel, dim3(blocks_for(sepaihrd_rng::LIBM_CHECK_N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int sampler_libm_check_count() { return sepaihrd_rng::LIBM_CHECK_N; }
+
 int sampler_seed_streams(const SamplerState& s, uint32_t seed0, void* stream) {
     hipLaunchKernelGGL(mh_seed_kernel, dim3(blocks_for((size_t)s.C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), s, seed0);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -829,6 +877,12 @@ int sampler_summary_records(const SamplerState& s, const double* d_best_lp, int 
     if (s.n_store <= 0 || first_sample < 0 || n_samples > s.n_store || first_sample >= n_samples) return -1;
     hipLaunchKernelGGL(mh_summary_kernel, dim3(blocks_for((size_t)s.C * s.P, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), s,
                        d_best_lp, first_sample, n_samples, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int sampler_snapshot(const SamplerState& s, const double* d_lp, const double* d_best_lp, const int32_t* d_chains, int n, int first,
+                     int count, double* d_out, void* stream) {
+    hipLaunchKernelGGL(mh_snapshot_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), s, d_lp, d_best_lp, d_chains, first, count, d_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

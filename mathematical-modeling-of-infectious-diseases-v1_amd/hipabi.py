@@ -17,7 +17,7 @@ from .problem import SEPAIHRDProblem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsepaihrd_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 LOWEST = -np.finfo(np.float64).max
 
 _dp = C.POINTER(C.c_double)
@@ -49,6 +49,7 @@ class sepaihrd_kernel_info(C.Structure):
         ("lanes_per_chain", C.c_int32), ("chains_per_wave", C.c_int32), ("block_threads", C.c_int32),
         ("vgprs", C.c_int32), ("sgprs", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32),
         ("max_blocks_per_cu", C.c_int32), ("num_cus", C.c_int32), ("likelihood_form", C.c_int32),
+        ("phase_pass_applied", C.c_int32),
         ("kernel_name", C.c_char * 128), ("device_name", C.c_char * 128),
     ]
 
@@ -92,6 +93,7 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_records_buffer", "sepaihrd_allgather_records", "sepaihrd_read_records", "sepaihrd_write_records",
     "sepaihrd_mh_seed_streams", "sepaihrd_mh_draw_first", "sepaihrd_mh_keep_scale_on_device", "sepaihrd_mh_read_run_state",
     "sepaihrd_mh_read_sample_values", "sepaihrd_mh_read_accept_trace",
+    "sepaihrd_device_libm_check", "sepaihrd_mh_read_failure_counts", "sepaihrd_mh_snapshot_begin", "sepaihrd_mh_snapshot_end",
 )
 
 _lib = None
@@ -170,6 +172,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_mh_read_run_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.sepaihrd_mh_read_sample_values.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.sepaihrd_mh_read_accept_trace.argtypes = [vp, vp]
+    lib.sepaihrd_device_libm_check.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.sepaihrd_mh_read_failure_counts.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.sepaihrd_mh_snapshot_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.sepaihrd_mh_snapshot_end.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.sepaihrd_mh_destroy.restype = None
     lib.sepaihrd_mh_destroy.argtypes = [vp]
     lib.sepaihrd_mh_evaluate_current.argtypes = [vp, vp, vp]
@@ -362,6 +368,13 @@ class HipObjective:
         self._check(self.lib.sepaihrd_apply_constraints(self.ctx, mode, th.ctypes.data, th.shape[0],
                                                         out.ctypes.data), "apply_constraints")
         return out
+
+    def device_libm_check(self):
+        """(n_log_diff, n_exp_diff): arguments of the run-time self-check on which the device's log / exp restatements
+        differ from this process's libm (0, 0 = the device may draw the chains' streams)."""
+        a, b = C.c_int32(-1), C.c_int32(-1)
+        self._check(self.lib.sepaihrd_device_libm_check(self.ctx, C.byref(a), C.byref(b)), "device_libm_check")
+        return a.value, b.value
 
     def kernel_info(self, batch: int = 0) -> dict:
         """Resource report of the integrator kernel a launch of `batch` chains uses (0: the large-batch kernel)."""

@@ -87,7 +87,9 @@ int main() {
         std::printf("initial log-likelihood   %.6f\n", calibrator.getInitialObjectiveValue());
 
         calibrator.calibrate({{"iterations", 25}, {"cloud_size_multiplier", 4}, {"threads", 8}, {"seed", 11}},
-                             {{"mcmc_iterations", 600}, {"burn_in", 200}, {"adaptation_period", 100}, {"thinning", 5}, {"seed", 12}},
+                             {{"mcmc_iterations", 600}, {"burn_in", 200}, {"adaptation_period", 100}, {"thinning", 5}, {"seed", 12},
+                              // the reference's reporting keys: a progress line every 200 iterations, no trace files from an example
+                              {"report_interval", 200}, {"write_checkpoints", 0}, {"write_trace", 0}},
                              /*chains=*/8);
         std::printf("phase 1 (hill climbing)  %.6f\n", calibrator.getPhase1Result().bestObjectiveValue);
         std::printf("best after MCMC          %.6f  (8 chains x 600 iterations)\n", calibrator.getBestObjectiveValue());

@@ -15,8 +15,11 @@
 #pragma once
 #include <cstdint>
 #include <deque>
+#include <functional>
+#include <map>
 #include <memory>
 #include <random>
+#include <string>
 #include <unordered_map>
 
 #include "AgeSEPAIHRDModel.hpp"
@@ -276,6 +279,26 @@ public:
     // generate_canonical, the polar method and glibc's log written out for it, csrc/sepaihrd_rng.inc -- the same values from
     // the same stream positions) or on the host (libstdc++ itself; what sets the pace beyond a few thousand chains)
     void setDeviceStreams(bool on) { device_streams_ = on; }
+    // The device's log / exp restate one libm build (glibc 2.35, x86-64, FMA variants).  Before a run lets the device draw,
+    // they are compared with this host's std::log / std::exp on 4096 fixed arguments (sepaihrd_device_libm_check); on any
+    // difference the run keeps draws and scale adaptation on the host, says so through the progress sink, and this is true.
+    bool deviceStreamsFellBack() const { return device_streams_fell_back_; }
+    // Progress reports and trace files of MetropolisHastingsSampler::optimize (MetropolisHastingsSampler.cpp:363-383,399-411,
+    // 440-469): every `report_interval` iterations the line "Iter: .. | LogPost: .. | Best: .. | AccRate: .. | Scale: .." and,
+    // with `write_checkpoints`, posterior_trace_checkpoint.csv (the last <= 5000 thinned samples); at the end
+    // posterior_trace_final.csv and, with `write_trace`, posterior_trace.csv -- all three settings keys are the reference's,
+    // with its defaults (100, 1, 1; report_interval <= 0 switches the reports off).  The reference has ONE chain: here the
+    // first `checkpoint_chains` chains (settings key, default 1) report and write; chain 0 uses the reference's file names,
+    // chain k > 0 gets `_chain<k>` in front of `.csv`.  A device-resident run does not wait for any of this: the values
+    // leave the device behind the iteration they belong to (sepaihrd_mh_snapshot_begin) and a writer thread formats them.
+    // Directory: <project root>/data/mcmc_samples like the reference (FileUtils::getProjectRoot's rule) unless set here.
+    void setOutputDirectory(const std::string& dir) { output_dir_ = dir; }
+    // where the progress lines go (default: stdout, in the layout of the reference's Logger); level is INFO or WARNING
+    void setProgressSink(std::function<void(const std::string& level, const std::string& message)> sink) { progress_sink_ = std::move(sink); }
+    // evaluations the accept tests of the last device-resident run saw fail: status 2 (500 rejections), 3 (attempt budget),
+    // 4 (hand-off guard of the evaluation kernel).  They count as -1e18 like a throwing objective; a non-zero last entry is
+    // an error of this build and makes the run throw.
+    const std::vector<long>& failureCounts() const { return failure_counts_; }
     const std::vector<std::vector<unsigned char>>& acceptTraces() const { return traces_; }
     void setKeepAcceptTraces(bool on) { keep_traces_ = on; }  // off for long runs of many chains (65 536 x 100 000 = 6.5 GB)
     // wall time of the iteration loop of the last device-resident run (proposal 1 staged .. last accept test), without
@@ -301,6 +324,14 @@ private:
     std::vector<double> summary_records_;  // [C][2 P + 2] of the last device-resident run
     std::vector<int> group_rows_;          // chains per group of the last grouped run
     int summary_width_ = 0;
+    int report_interval_ = 100, checkpoint_chains_ = 1;
+    bool write_checkpoints_ = true, write_trace_ = true;
+    std::string output_dir_;
+    std::function<void(const std::string&, const std::string&)> progress_sink_;
+    bool device_streams_fell_back_ = false;
+    std::vector<long> failure_counts_;
+    struct Reporter;
+    friend struct Reporter;
 };
 
 }  // namespace epidemic

@@ -19,7 +19,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
 #include <limits>
+#include <sstream>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -176,6 +181,131 @@ inline void draw_standard_normals(std::mt19937& g, double* dst, int P) {
 inline double sanitize(double v) { return (std::isnan(v) || std::isinf(v)) ? -1e18 : v; }  // safeEvaluate :65-74
 }  // namespace
 
+namespace {
+// FileUtils::getProjectRoot (src/utils/FileUtils.cpp:24-45): the working directory or the nearest of its five parents
+// that holds data/, include/ and src/; else the working directory
+std::string project_root() {
+    namespace fs = std::filesystem;
+    std::error_code ec;
+    fs::path cur = fs::current_path(ec);
+    if (ec) return ".";
+    std::vector<fs::path> roots{cur};
+    fs::path p = cur;
+    for (int i = 0; i < 5; ++i) {
+        p = p.parent_path();
+        if (!p.empty()) roots.push_back(p);
+    }
+    for (const fs::path& r : roots)
+        if (fs::exists(r / "data", ec) && fs::exists(r / "include", ec) && fs::exists(r / "src", ec)) return fs::absolute(r).lexically_normal().string();
+    return fs::absolute(cur).lexically_normal().string();
+}
+// the reference's Logger::formatLogMessage (include/utils/Logger.hpp:143-160)
+std::string logger_line(const std::string& level, const std::string& source, const std::string& message) {
+    std::ostringstream oss;
+    const std::time_t now = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+    std::tm tm_buf{};
+    localtime_r(&now, &tm_buf);
+    oss << std::put_time(&tm_buf, "%Y-%m-%d %H:%M:%S") << " " << (level == "WARNING" ? "[WARNING]" : "[INFO]   ") << " [" << source << "] " << message;
+    return oss.str();
+}
+}  // namespace
+
+// Progress lines and trace files of one run (MetropolisHastingsSampler.cpp:363-383,399-411,440-469) for the first k chains.
+// The samples of a reported chain accumulate here as they arrive (host loops hand them over as they are stored, the
+// device-resident loop in snapshots), so a checkpoint is always written from host memory.
+struct MultiChainMetropolisHastings::Reporter {
+    const MultiChainMetropolisHastings& mh;
+    std::vector<std::string> names;
+    int P = 0, k = 0;
+    std::string dir;
+    std::vector<std::vector<double>> samples, values;  // per reported chain: [n][P], [n]
+    Reporter(const MultiChainMetropolisHastings& owner, IParameterManager& pm, int C) : mh(owner), names(pm.getParameterNames()) {
+        P = static_cast<int>(pm.getParameterCount());
+        k = std::max(0, std::min(owner.checkpoint_chains_, C));
+        samples.assign(static_cast<size_t>(k), {});
+        values.assign(static_cast<size_t>(k), {});
+        if (filesWanted()) dir = owner.output_dir_.empty() ? project_root() + "/data/mcmc_samples" : owner.output_dir_;
+    }
+    bool reportsWanted() const { return k > 0 && mh.report_interval_ > 0; }
+    bool filesWanted() const { return k > 0 && mh.store_samples_ && (mh.write_checkpoints_ || mh.write_trace_); }
+    bool due(int t) const { return reportsWanted() && (t + 1) % mh.report_interval_ == 0; }  // :363
+    void say(const std::string& level, const std::string& msg) const {
+        if (mh.progress_sink_) mh.progress_sink_(level, msg);
+        else std::cout << logger_line(level, "MetropolisHastingsSampler", msg) << std::endl;
+    }
+    void append(int chain, const double* rows, const double* vals, size_t n) {
+        samples[static_cast<size_t>(chain)].insert(samples[static_cast<size_t>(chain)].end(), rows, rows + n * static_cast<size_t>(P));
+        values[static_cast<size_t>(chain)].insert(values[static_cast<size_t>(chain)].end(), vals, vals + n);
+    }
+    // the progress line of iteration t for reported chain `chain` (:364-379)
+    void line(int chain, int t, double lp, double best, long accepted, double scale) const {
+        const double acc_rate = static_cast<double>(accepted) / (t + 1);
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "%sIter: %6d | LogPost: %.2f | Best: %.2f | AccRate: %.1f%% | Scale: %.3f",
+                      chain > 0 ? ("[chain " + std::to_string(chain) + "] ").c_str() : "", t + 1, lp, best, acc_rate * 100.0, scale);
+        say("INFO", buf);
+        if (t > mh.burn_in_ && acc_rate < 0.05) say("WARNING", "Acceptance rate low (<5%). Scale adaptation working to correct.");
+        else if (t > mh.burn_in_ && acc_rate > 0.50) say("WARNING", "Acceptance rate high (>50%). Scale adaptation working to correct.");
+    }
+    std::string path(const std::string& stem, int chain) const {
+        return dir + "/" + stem + (chain > 0 ? "_chain" + std::to_string(chain) : "") + ".csv";
+    }
+    // saveCheckpoint / saveSamplesToCSV (:414-469): `iter,log_posterior,<names>`, rows `i,value,theta...` in
+    // std::scientific << setprecision(6) (the manipulators stay set for the parameters); checkpoint: the last <= 5000 samples
+    void writeFile(const std::string& file, int chain, size_t first) const {
+        std::error_code ec;
+        std::filesystem::create_directories(dir, ec);
+        // written under another name and moved into place: a reader never sees half a checkpoint
+        const std::string tmp = file + ".part";
+        {
+            std::ofstream out(tmp);
+            if (!out.is_open()) { say("WARNING", "Failed to open CSV for writing: " + file); return; }
+            out << "iter,log_posterior";
+            for (const std::string& n : names) out << "," << n;
+            out << "\n";
+            const std::vector<double>& s = samples[static_cast<size_t>(chain)];
+            const std::vector<double>& v = values[static_cast<size_t>(chain)];
+            std::string row;
+            char num[40];
+            for (size_t i = first; i < v.size(); ++i) {
+                row = std::to_string(i);
+                std::snprintf(num, sizeof(num), ",%.6e", v[i]);
+                row += num;
+                for (int j = 0; j < P; ++j) {
+                    std::snprintf(num, sizeof(num), ",%.6e", s[i * static_cast<size_t>(P) + j]);
+                    row += num;
+                }
+                row += "\n";
+                out << row;
+            }
+        }
+        std::filesystem::rename(tmp, file, ec);
+        if (ec) say("WARNING", "Failed to move " + tmp + " to " + file);
+    }
+    void checkpoint() const {  // :380-382 -> saveCheckpoint(result, pm, false)
+        if (!(mh.write_checkpoints_ && mh.store_samples_)) return;
+        for (int c = 0; c < k; ++c) {
+            const size_t n = values[static_cast<size_t>(c)].size();
+            if (n == 0) continue;
+            writeFile(path("posterior_trace_checkpoint", c), c, n > 5000 ? n - 5000 : 0);
+        }
+    }
+    void finish() const {  // :399-411
+        if (!mh.store_samples_) return;
+        for (int c = 0; c < k; ++c) {
+            if (values[static_cast<size_t>(c)].empty()) continue;
+            if (mh.write_checkpoints_) {
+                writeFile(path("posterior_trace_final", c), c, 0);
+                say("INFO", "Full posterior trace saved to: " + path("posterior_trace_final", c));
+            }
+            if (mh.write_trace_) {
+                writeFile(path("posterior_trace", c), c, 0);
+                say("INFO", "Full posterior trace saved to: " + path("posterior_trace", c));
+            }
+        }
+    }
+};
+
 void MultiChainMetropolisHastings::configure(const std::map<std::string, double>& settings) {
     auto get = [&](const char* key, double def) {
         auto it = settings.find(key);
@@ -195,6 +325,11 @@ void MultiChainMetropolisHastings::configure(const std::map<std::string, double>
     adaptation_window_ = static_cast<int>(get("adaptation_window", static_cast<double>(adaptation_window_)));
     device_streams_ = get("device_streams", device_streams_ ? 1.0 : 0.0) != 0.0;
     keep_traces_ = get("keep_accept_traces", keep_traces_ ? 1.0 : 0.0) != 0.0;
+    // the reference's reporting and I/O keys (MetropolisHastingsSampler.cpp:34,41-43), and how many chains they cover here
+    report_interval_ = static_cast<int>(get("report_interval", 100.0));
+    write_checkpoints_ = get("write_checkpoints", 1.0) != 0.0;
+    write_trace_ = get("write_trace", 1.0) != 0.0;
+    checkpoint_chains_ = static_cast<int>(get("checkpoint_chains", static_cast<double>(checkpoint_chains_)));
 }
 
 OptimizationResult MultiChainMetropolisHastings::optimize(const Eigen::VectorXd& x0, IObjectiveFunction& objective,
@@ -269,6 +404,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
     eval(batch.data(), C, values.data());  // initial state :257
 
     std::vector<OptimizationResult> results(static_cast<size_t>(C));
+    Reporter reporter(*this, pm, C);
     traces_.assign(static_cast<size_t>(C), {});
     auto to_eigen = [P](const std::vector<double>& v) {
         Eigen::VectorXd e(P);
@@ -286,6 +422,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         r.bestParameters = to_eigen(ch.x);
         r.bestObjectiveValue = ch.lp;
         if (keep_traces_) traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
+        if (store_samples_ && c < reporter.k) reporter.append(c, ch.x.data(), &ch.lp, 1);
     }
 
     for (int t = 1; t < iterations_; ++t) {
@@ -415,6 +552,13 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
                 r.sampleObjectiveValues.push_back(ch.lp);
             }
         }
+        // ---- 8: logging and checkpointing of the reported chains (:362-383)
+        for (int c = 0; c < reporter.k; ++c) {
+            const Chain& ch = chains[static_cast<size_t>(c)];
+            if (store_samples_ && (t % thinning_ == 0)) reporter.append(c, ch.x.data(), &ch.lp, 1);
+            if (reporter.due(t)) reporter.line(c, t, ch.lp, results[static_cast<size_t>(c)].bestObjectiveValue, ch.accepted, ch.scale);
+        }
+        if (reporter.due(t)) reporter.checkpoint();
     }
 
     for (int c = 0; c < C; ++c) {
@@ -429,6 +573,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::run(const std::vec
         r.additionalStats["burn_in"] = static_cast<double>(burn_in_);
         r.additionalStats["total_iterations"] = static_cast<double>(iterations_);
     }
+    reporter.finish();
     return results;
 }
 
@@ -459,6 +604,22 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     for (int i = 0; i < P; ++i) cov0[static_cast<size_t>(i) * P + i] += regularization_epsilon_;
 
     sepaihrd_ctx* ctx = objective.deviceContext();
+    Reporter reporter(*this, pm, C);
+    // the device may draw the streams only if its log / exp ARE this host's libm (sepaihrd_device_libm_check)
+    bool device_streams = this->device_streams_;
+    device_streams_fell_back_ = false;
+    if (device_streams) {
+        int32_t n_log = 0, n_exp = 0;
+        if (sepaihrd_device_libm_check(ctx, &n_log, &n_exp) != SEPAIHRD_OK)
+            throw ModelException("MetropolisHastingsSampler", std::string("sepaihrd_device_libm_check: ") + sepaihrd_last_error(ctx));
+        if (n_log != 0 || n_exp != 0) {
+            device_streams = false;
+            device_streams_fell_back_ = true;
+            reporter.say("WARNING", "the device's log / exp differ from this host's libm on " + std::to_string(n_log) + " (log) and " +
+                                        std::to_string(n_exp) + " (exp) of 4096 self-check arguments (csrc/sepaihrd_rng.inc restates glibc 2.35's "
+                                        "x86-64 FMA variants): random streams and scale adaptation stay on the host for this run");
+        }
+    }
     sepaihrd_mh_config mcfg{};
     mcfg.chains = C;
     mcfg.iterations = std::max(iterations_, 1);
@@ -541,7 +702,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         ch.recent.assign(1000, 0);
         if (store_samples_) ch.sample_values.push_back(ch.lp);
         if (keep_traces_) traces_[static_cast<size_t>(c)].reserve(static_cast<size_t>(std::max(iterations_ - 1, 0)));
-        if (!device_streams_) ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
+        if (!device_streams) ch.rng.consume(draw_normals(ch.rng, 0, &z_next[static_cast<size_t>(c) * P]));  // proposal 1
         scale[static_cast<size_t>(c)] = ch.scale;
     }
 
@@ -563,7 +724,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     // at the start of the next evaluation and does its bookkeeping for iteration t while evaluation t + 1 runs.
     // With the streams on the device the scale adaptation goes there too (adaptGlobalScale in the test kernel): the sampler is
     // self-contained, this loop only queues iterations, and what the host kept per chain is read back at the end
-    if (device_streams_) check(sepaihrd_mh_keep_scale_on_device(mh, adapt_scale_ ? 1 : 0, target_acceptance_rate_, keep_traces_ ? 1 : 0), "mh_keep_scale_on_device");
+    if (device_streams) check(sepaihrd_mh_keep_scale_on_device(mh, adapt_scale_ ? 1 : 0, target_acceptance_rate_, keep_traces_ ? 1 : 0), "mh_keep_scale_on_device");
     check(sepaihrd_mh_set_values(mh, values.data()), "mh_set_values");
     double* const test = sepaihrd_mh_test_buffer(mh);  // [log_u C][scale if rejected C][scale if accepted C][z_plain C*P]
     double* const t_log_u = test;
@@ -579,7 +740,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             const uint8_t f = flags[static_cast<size_t>(c)];
             const bool acc = (f & 1) != 0;
             // the stream moves by what the continuation taken drew: no uniform (bit 2) -> the plain normals only
-            if (!device_streams_) ch.rng.consume((f & 4) ? (drew_next ? ch.used_alt : 0) : ch.used_likely);
+            if (!device_streams) ch.rng.consume((f & 4) ? (drew_next ? ch.used_alt : 0) : ch.used_likely);
             if (acc) {
                 ch.lp = values[static_cast<size_t>(c)];
                 ch.accepted++;
@@ -600,10 +761,33 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             if (store_samples_ && (t % thinning_ == 0)) ch.sample_values.push_back(ch.lp);
         }
     };
+    // reports and checkpoints of the first reporter.k chains
+    std::vector<int32_t> rep_chains(static_cast<size_t>(reporter.k));
+    for (int c = 0; c < reporter.k; ++c) rep_chains[static_cast<size_t>(c)] = c;
+    int rep_fetched = 0;  // samples of the reported chains already handed to the reporter
+    // host-side streams: the host has the chains' values, counts and scales of iteration t; the new samples of the reported
+    // chains come through the same snapshot, waited for at once (this loop waits for the device every iteration anyway)
+    auto report_from_host = [&](int t) {
+        const int ns_now = store_samples_ ? std::min(sepaihrd_mh_sample_count(mh), t / thinning_ + 1) : 0;
+        const int count = std::max(ns_now - rep_fetched, 0);
+        const size_t k = static_cast<size_t>(reporter.k), n = static_cast<size_t>(count);
+        std::vector<double> smp(k * n * P);
+        if (n) {
+            check(sepaihrd_mh_snapshot_begin(mh, rep_chains.data(), reporter.k, rep_fetched, count), "mh_snapshot_begin");
+            check(sepaihrd_mh_snapshot_end(mh, 1, nullptr, smp.data(), nullptr), "mh_snapshot_end");
+        }
+        for (size_t c = 0; c < k; ++c) {
+            const Light& ch = chains[c];
+            if (n) reporter.append(static_cast<int>(c), &smp[c * n * P], &ch.sample_values[static_cast<size_t>(rep_fetched)], n);
+            reporter.line(static_cast<int>(c), t, ch.lp, ch.best, ch.accepted, ch.scale);
+        }
+        rep_fetched = ns_now;
+        reporter.checkpoint();
+    };
     const auto loop_begin = now();
-    if (device_streams_) check(sepaihrd_mh_seed_streams(mh, seed_), "mh_seed_streams");  // chain c: mt19937(seed + c), as the host's
+    if (device_streams) check(sepaihrd_mh_seed_streams(mh, seed_), "mh_seed_streams");  // chain c: mt19937(seed + c), as the host's
     if (iterations_ > 1) {  // proposal 1: nothing to test yet
-        if (device_streams_) {
+        if (device_streams) {
             check(sepaihrd_mh_draw_first(mh), "mh_draw_first");
         } else {
             check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
@@ -611,9 +795,40 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         }
         check(sepaihrd_mh_step(mh, nullptr, scale.data(), nullptr, nullptr, 0, 10.0 / (1 + 100.0), adapt_mode(1)), "mh_step");
     }
-    if (device_streams_) {
-        for (int t = 1; t < iterations_; ++t)
+    if (device_streams) {
+        // The run is queued ahead of the device; a report must not wait for it.  Behind the iteration it belongs to, a gather of
+        // the reported chains' values and new samples is queued and copied home on a stream of its own
+        // (sepaihrd_mh_snapshot_begin); a writer thread waits for THAT, formats the line and rewrites the checkpoint file.
+        std::thread writer;
+        std::string writer_error;
+        auto queue_report = [&](int t) {
+            if (writer.joinable()) writer.join();  // one snapshot in flight; reports are report_interval iterations apart
+            if (!writer_error.empty()) throw ModelException("MetropolisHastingsSampler", writer_error);
+            const int ns_now = store_samples_ ? sepaihrd_mh_sample_count(mh) : 0;
+            const int first = rep_fetched, count = std::max(ns_now - rep_fetched, 0);
+            check(sepaihrd_mh_snapshot_begin(mh, rep_chains.data(), reporter.k, first, count), "mh_snapshot_begin");
+            rep_fetched = ns_now;
+            writer = std::thread([&, t, count]() {
+                const size_t k = static_cast<size_t>(reporter.k), n = static_cast<size_t>(count);
+                std::vector<double> state(4 * k), smp(k * n * P), vals(k * n);
+                if (sepaihrd_mh_snapshot_end(mh, 1, state.data(), n ? smp.data() : nullptr, n ? vals.data() : nullptr) != SEPAIHRD_OK) {
+                    writer_error = "sepaihrd_mh_snapshot_end failed";
+                    return;
+                }
+                for (size_t c = 0; c < k; ++c) {
+                    if (n) reporter.append(static_cast<int>(c), &smp[c * n * P], &vals[c * n], n);
+                    reporter.line(static_cast<int>(c), t, state[4 * c], state[4 * c + 1], static_cast<long>(state[4 * c + 3]), state[4 * c + 2]);
+                }
+                reporter.checkpoint();
+            });
+        };
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{writer};
+        for (int t = 1; t < iterations_; ++t) {
             check(sepaihrd_mh_step_tested(mh, 10.0 / ((t + 1) + 100.0), adapt_mode(t + 1), t + 1 < iterations_ ? 0 : 1), "mh_step_tested");
+            if (reporter.due(t)) queue_report(t);
+        }
+        if (writer.joinable()) writer.join();
+        if (!writer_error.empty()) throw ModelException("MetropolisHastingsSampler", writer_error);
         std::vector<double> lp_all(static_cast<size_t>(C)), best_all(static_cast<size_t>(C)), scale_all(static_cast<size_t>(C));
         std::vector<int32_t> acc_all(static_cast<size_t>(C)), emergency_all(static_cast<size_t>(C));
         check(sepaihrd_mh_read_run_state(mh, lp_all.data(), best_all.data(), scale_all.data(), acc_all.data(), emergency_all.data()), "mh_read_run_state");  // waits
@@ -653,6 +868,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
             const auto p0b = now();
             t_wait += secs(p0, p0b);
             book(t - 1, true);
+            if (reporter.due(t - 1)) report_from_host(t - 1);
             t_book += secs(p0b, now());
         }
         const auto p1 = now();
@@ -660,7 +876,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int c = 0; c < C; ++c) {
             Light& ch = chains[static_cast<size_t>(c)];
-            if (!device_streams_) {
+            if (!device_streams) {
                 // uniform_real_distribution<double>(0, 1) returns the canonical itself (c * (1 - 0) + 0)
                 ch.log_u = std::log(ch.rng.at(0));                                     // :327
                 t_log_u[c] = ch.log_u;
@@ -679,7 +895,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
                 t_scale_reject[c] = t_scale_accept[c] = ch.scale;
             }
         }
-        if (more && !device_streams_) {
+        if (more && !device_streams) {
             check(sepaihrd_mh_stage_normals(mh, z_next), "mh_stage_normals");
             z_next = sepaihrd_mh_staging_buffer(mh);
         }
@@ -692,6 +908,7 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
     if (iterations_ > 1) {
         check(sepaihrd_mh_fetch_test(mh, values.data(), flags.data()), "mh_fetch_test");
         book(iterations_ - 1, false);
+        if (reporter.due(iterations_ - 1)) report_from_host(iterations_ - 1);
     }
     last_loop_seconds_ = secs(loop_begin, now());
     }  // host-side streams
@@ -747,6 +964,24 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainsOnDe
         r.additionalStats["burn_in"] = static_cast<double>(burn_in_);
         r.additionalStats["total_iterations"] = static_cast<double>(iterations_);
     }
+    {   // evaluations the accept tests saw FAIL (they counted as -1e18, like an objective that throws)
+        int64_t fc[3] = {0, 0, 0};
+        check(sepaihrd_mh_read_failure_counts(mh, fc), "mh_read_failure_counts");
+        failure_counts_.assign({static_cast<long>(fc[0]), static_cast<long>(fc[1]), static_cast<long>(fc[2])});
+        for (OptimizationResult& r : results) r.additionalStats["failed_evaluations_all_chains"] = static_cast<double>(fc[0] + fc[1] + fc[2]);
+        if (fc[0] + fc[1] > 0)
+            reporter.say("WARNING", std::to_string(fc[0]) + " evaluations ended in odeint's 500 consecutive step rejections and " + std::to_string(fc[1]) +
+                                        " in the attempt budget; their proposals were rejected like an objective that throws");
+        if (fc[2] > 0)
+            throw ModelException("MetropolisHastingsSampler", std::to_string(fc[2]) + " evaluations reported SEPAIHRD_STATUS_PIPELINE (the hand-off between an "
+                                 "integrating wave and its likelihood wave timed out): a defect of the evaluation kernel, not of the model -- the run's accept decisions are not to be trusted");
+    }
+    // the trace files of the reported chains, from everything the run stored (:399-411)
+    for (int c = 0; c < reporter.k && ns > 0; ++c) {
+        reporter.samples[static_cast<size_t>(c)].assign(rows.begin() + static_cast<size_t>(c) * ns * P, rows.begin() + static_cast<size_t>(c + 1) * ns * P);
+        reporter.values[static_cast<size_t>(c)] = chains[static_cast<size_t>(c)].sample_values;
+    }
+    reporter.finish();
     return results;
 }
 
@@ -786,6 +1021,8 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
     std::vector<std::string> errors(static_cast<size_t>(G));
     std::vector<double> loop_secs(static_cast<size_t>(G), 0.0);
     std::vector<std::vector<double>> part_records(static_cast<size_t>(G));
+    std::vector<int> fell_back(static_cast<size_t>(G), 0);
+    std::vector<std::vector<long>> part_failures(static_cast<size_t>(G));
     std::vector<std::thread> workers;
     for (int g = 0; g < G; ++g) {
         workers.emplace_back([&, g]() {
@@ -793,12 +1030,15 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
                 MultiChainMetropolisHastings local = *this;  // settings + initial covariance
                 local.seed_ = seed_ + static_cast<uint32_t>(first[static_cast<size_t>(g)]);
                 local.host_threads_ = std::max(1, share / G);
+                if (g > 0) local.checkpoint_chains_ = 0;  // the reports and trace files cover the run's first chains: group 0's
                 const int c0 = first[static_cast<size_t>(g)], c1 = first[static_cast<size_t>(g) + 1];
                 const std::vector<double> init(initial.begin() + static_cast<size_t>(c0) * P, initial.begin() + static_cast<size_t>(c1) * P);
                 parts[static_cast<size_t>(g)] = local.optimizeChainsOnDevice(init, c1 - c0, *objectives[static_cast<size_t>(g)], pm);
                 part_traces[static_cast<size_t>(g)] = local.traces_;
                 part_records[static_cast<size_t>(g)] = local.summary_records_;
                 loop_secs[static_cast<size_t>(g)] = local.last_loop_seconds_;
+                fell_back[static_cast<size_t>(g)] = local.device_streams_fell_back_ ? 1 : 0;
+                part_failures[static_cast<size_t>(g)] = local.failure_counts_;
             } catch (const std::exception& e) { errors[static_cast<size_t>(g)] = e.what(); }
         });
     }
@@ -808,6 +1048,10 @@ std::vector<OptimizationResult> MultiChainMetropolisHastings::optimizeChainGroup
     std::vector<OptimizationResult> results;
     traces_.clear();
     last_loop_seconds_ = *std::max_element(loop_secs.begin(), loop_secs.end());
+    device_streams_fell_back_ = std::any_of(fell_back.begin(), fell_back.end(), [](int v) { return v != 0; });
+    failure_counts_.assign(3, 0);
+    for (const std::vector<long>& f : part_failures)
+        for (size_t k = 0; k < f.size() && k < 3; ++k) failure_counts_[k] += f[k];
     summary_records_.clear();
     summary_width_ = 2 * P + 2;
     group_rows_.clear();

@@ -2,6 +2,7 @@
 // The layout of `sepaihrd_problem` is reused as the carrier of the model / data arrays.
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <sstream>
 
 #include "epidemic_hip/BatchedHillClimbing.hpp"
@@ -261,7 +262,7 @@ int host_mh_run(void* hv, int C, const double* initial, uint32_t seed, int itera
     try {
         const int P = static_cast<int>(h->pm->getParameterCount());
         MultiChainMetropolisHastings mh;
-        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"report_interval", 0.0}, {"write_checkpoints", 0.0}, {"write_trace", 0.0}, {"burn_in", double(burn_in)},
                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                       {"regularization_epsilon", reg_eps}, {"target_acceptance_rate", target_acc},
                       {"adapt_scale", double(adapt_scale)}, {"store_samples", 1.0},
@@ -414,7 +415,7 @@ int host_calibrate(void* hv, int hc_iterations, int cloud_size_multiplier, int t
         HipModelCalibrator cal(*h->pm, *h->obj);
         cal.calibrate({{"iterations", double(hc_iterations)}, {"cloud_size_multiplier", double(cloud_size_multiplier)},
                        {"threads", double(threads)}, {"seed", double(hc_seed)}},
-                      {{"mcmc_iterations", double(mh_iterations)}, {"burn_in", double(burn_in)},
+                      {{"mcmc_iterations", double(mh_iterations)}, {"report_interval", 0.0}, {"write_checkpoints", 0.0}, {"write_trace", 0.0}, {"burn_in", double(burn_in)},
                        {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                        {"seed", double(mh_seed)}, {"store_samples", 1.0}},
                       chains);
@@ -442,7 +443,7 @@ int host_calibrate_pso(void* hv, const char* const* keys, const double* values, 
         HipModelCalibrator cal(*h->pm, *h->obj);
         cal.setPhase1Algorithm(std::make_unique<BatchedParticleSwarmOptimization>());
         cal.calibrate(phase1,
-                      {{"mcmc_iterations", double(mh_iterations)}, {"burn_in", double(burn_in)},
+                      {{"mcmc_iterations", double(mh_iterations)}, {"report_interval", 0.0}, {"write_checkpoints", 0.0}, {"write_trace", 0.0}, {"burn_in", double(burn_in)},
                        {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                        {"seed", double(mh_seed)}, {"store_samples", 1.0}},
                       chains);
@@ -537,6 +538,72 @@ void host_glibc_exp(const double* x, int n, double* out) {
     for (int i = 0; i < n; ++i) out[i] = sepaihrd_rng::glibc_exp(x[i]);
 }
 
+// The device-resident sampler with the reference's reporting and trace files switched ON (MetropolisHastingsSampler.cpp:
+// 363-383,399-411,440-469): progress lines into `log_path` (one per line), files into `dir`; device_streams = 0 draws on the
+// host.  Outputs: every chain's samples [C][n_samples][P] and their values, *fell_back (the libm self-check refused the
+// device streams), failure counts [3].
+int host_mh_run_reported(void* hv, int C, const double* initial, uint32_t seed, int iterations, int burn_in, int adaptation_period,
+                         int thinning, int report_interval, int checkpoint_chains, int device_state, int device_streams,
+                         const char* dir, const char* log_path, double* samples, double* sample_values, int32_t* n_samples,
+                         int* fell_back, long* failures) {
+    auto* h = static_cast<HostHandle*>(hv);
+    try {
+        const int P = static_cast<int>(h->pm->getParameterCount());
+        MultiChainMetropolisHastings mh;
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)}, {"adaptation_period", double(adaptation_period)},
+                      {"thinning", double(thinning)}, {"report_interval", double(report_interval)}, {"write_checkpoints", 1.0},
+                      {"write_trace", 1.0}, {"checkpoint_chains", double(checkpoint_chains)}, {"device_streams", double(device_streams)},
+                      {"keep_accept_traces", 0.0}});
+        mh.setSeed(seed);
+        mh.setOutputDirectory(dir ? dir : "");
+        std::ofstream log;
+        if (log_path) {
+            log.open(log_path);
+            mh.setProgressSink([&log](const std::string& level, const std::string& msg) { log << level << " " << msg << std::endl; });
+        }
+        const std::vector<double> init(initial, initial + static_cast<size_t>(C) * P);
+        const std::vector<OptimizationResult> res = device_state ? mh.optimizeChainsOnDevice(init, C, *h->obj, *h->pm)
+                                                                 : mh.optimizeChains(init, C, *h->obj, *h->pm);
+        const int ns = static_cast<int>(res[0].samples.size());
+        if (n_samples) *n_samples = ns;
+        for (int c = 0; c < C; ++c)
+            for (int s = 0; s < ns; ++s) {
+                if (samples)
+                    for (int i = 0; i < P; ++i) samples[(static_cast<size_t>(c) * ns + s) * P + i] = res[static_cast<size_t>(c)].samples[static_cast<size_t>(s)][i];
+                if (sample_values) sample_values[static_cast<size_t>(c) * ns + s] = res[static_cast<size_t>(c)].sampleObjectiveValues[static_cast<size_t>(s)];
+            }
+        if (fell_back) *fell_back = mh.deviceStreamsFellBack() ? 1 : 0;
+        if (failures)
+            for (size_t k = 0; k < 3; ++k) failures[k] = k < mh.failureCounts().size() ? mh.failureCounts()[k] : 0;
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// The host twin of sepaihrd_device_libm_check (no GPU): csrc/sepaihrd_rng.inc's log / exp compiled for the host, on the SAME
+// fixed arguments, against this process's std::log / std::exp.  Counts of differing arguments.
+void host_libm_selfcheck(int* n_args, int* n_log_diff, int* n_exp_diff) {
+    int dl = 0, de = 0;
+    for (int i = 0; i < sepaihrd_rng::LIBM_CHECK_N; ++i) {
+        volatile double xl = sepaihrd_rng::libm_check_log_arg(i), xe = sepaihrd_rng::libm_check_exp_arg(i);
+        const double a = sepaihrd_rng::glibc_log(xl), b = std::log(xl), c = sepaihrd_rng::glibc_exp(xe), d = std::exp(xe);
+        if (std::memcmp(&a, &b, sizeof(double)) != 0) ++dl;
+        if (std::memcmp(&c, &d, sizeof(double)) != 0) ++de;
+    }
+    if (n_args) *n_args = sepaihrd_rng::LIBM_CHECK_N;
+    if (n_log_diff) *n_log_diff = dl;
+    if (n_exp_diff) *n_exp_diff = de;
+}
+// the self-check arguments themselves (tests look at what they cover)
+void host_libm_selfcheck_args(double* log_args, double* exp_args) {
+    for (int i = 0; i < sepaihrd_rng::LIBM_CHECK_N; ++i) {
+        log_args[i] = sepaihrd_rng::libm_check_log_arg(i);
+        exp_args[i] = sepaihrd_rng::libm_check_exp_arg(i);
+    }
+}
+
 // SEPAIHRD_ARITH_* the reference-shaped constructors select (environment SEPAIHRD_ARITH): what bench.py's default --arith
 // must equal (tests/test_host_logic.py)
 int host_default_arith() { return HipSEPAIHRDObjectiveFunction::defaultArithmeticIsFma() ? SEPAIHRD_ARITH_FMA : SEPAIHRD_ARITH_STRICT; }
@@ -566,7 +633,7 @@ int host_mh_groups_summaries(void** handles, int G, int C, const double* initial
         std::vector<HipSEPAIHRDObjectiveFunction*> objs;
         for (int g = 0; g < G; ++g) objs.push_back(static_cast<HostHandle*>(handles[g])->obj.get());
         MultiChainMetropolisHastings mh;
-        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"report_interval", 0.0}, {"write_checkpoints", 0.0}, {"write_trace", 0.0}, {"burn_in", double(burn_in)},
                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)}, {"store_samples", 1.0}});
         mh.setSeed(seed);
         const std::vector<OptimizationResult> res =
@@ -607,7 +674,7 @@ int host_mh_run_groups(void** handles, int G, int C, const double* initial, uint
         std::vector<HipSEPAIHRDObjectiveFunction*> objs;
         for (int g = 0; g < G; ++g) objs.push_back(static_cast<HostHandle*>(handles[g])->obj.get());
         MultiChainMetropolisHastings mh;
-        mh.configure({{"mcmc_iterations", double(iterations)}, {"burn_in", double(burn_in)},
+        mh.configure({{"mcmc_iterations", double(iterations)}, {"report_interval", 0.0}, {"write_checkpoints", 0.0}, {"write_trace", 0.0}, {"burn_in", double(burn_in)},
                       {"adaptation_period", double(adaptation_period)}, {"thinning", double(thinning)},
                       {"store_samples", 0.0}});
         mh.setSeed(seed);

@@ -258,6 +258,28 @@ class HostObjective:
         self.lib.host_current_parameters(self.h, out.ctypes.data)
         return out
 
+    def metropolis_hastings_reported(self, initial, seed: int, iterations: int, burn_in: int, out_dir: str, log_path: str,
+                                     adaptation_period: int = 100, thinning: int = 1, report_interval: int = 100,
+                                     checkpoint_chains: int = 1, device_state: bool = True, device_streams: bool = True) -> dict:
+        """The sampler with the reference's progress reports and trace files ON (MetropolisHastingsSampler.cpp:363-383,
+        399-411,440-469): lines into log_path, posterior_trace_checkpoint.csv / _final.csv / posterior_trace.csv into out_dir."""
+        x0 = np.ascontiguousarray(np.atleast_2d(initial), dtype=np.float64)
+        Cn, P = x0.shape
+        n_s = 1 + (max(iterations, 1) - 1) // max(1, thinning)
+        samples, values = np.zeros((Cn, n_s, P)), np.zeros((Cn, n_s))
+        ns, fb = C.c_int32(), C.c_int()
+        failures = (C.c_long * 3)()
+        self.lib.host_mh_run_reported.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32] + [C.c_int] * 8 + \
+            [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        rc = self.lib.host_mh_run_reported(self.h, Cn, x0.ctypes.data, seed, iterations, burn_in, adaptation_period, thinning,
+                                           report_interval, checkpoint_chains, int(device_state), int(device_streams),
+                                           out_dir.encode(), log_path.encode(), samples.ctypes.data, values.ctypes.data,
+                                           C.byref(ns), C.byref(fb), failures)
+        if rc:
+            raise RuntimeError(self.lib.host_last_error().decode())
+        assert ns.value == n_s
+        return {"samples": samples, "sample_values": values, "fell_back": bool(fb.value), "failures": list(failures)}
+
     def metropolis_hastings(self, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,
                             thinning: int = 1, reg_eps: float = 1e-6, target_acc: float = 0.234,
                             adapt_scale: bool = True, scalar_interface: bool = False, device_state: bool = False,
@@ -293,6 +315,21 @@ class HostObjective:
                 "accept_trace": trace[:, :iterations - 1] if want_trace else None, "samples": samples,
                 "sample_values": values, "final_cov": cov,
                 "loop_seconds": float(self.lib.host_last_mh_loop_seconds())}
+
+
+def libm_selfcheck() -> dict:
+    """The host twin of sepaihrd_device_libm_check (no device): csrc/sepaihrd_rng.inc's log / exp compiled for the host
+    against this process's std::log / std::exp on the self-check arguments; also returns the arguments."""
+    lib = load_library()
+    n, dl, de = C.c_int(), C.c_int(), C.c_int()
+    lib.host_libm_selfcheck.argtypes = [C.POINTER(C.c_int)] * 3
+    lib.host_libm_selfcheck.restype = None
+    lib.host_libm_selfcheck(C.byref(n), C.byref(dl), C.byref(de))
+    la, ea = np.empty(n.value), np.empty(n.value)
+    lib.host_libm_selfcheck_args.argtypes = [C.c_void_p, C.c_void_p]
+    lib.host_libm_selfcheck_args.restype = None
+    lib.host_libm_selfcheck_args(la.ctypes.data, ea.ctypes.data)
+    return {"n": n.value, "log_diff": dl.value, "exp_diff": de.value, "log_args": la, "exp_args": ea}
 
 
 def metropolis_hastings_groups(objectives, initial, seed: int, iterations: int, burn_in: int, adaptation_period: int = 100,

@@ -814,3 +814,157 @@ def test_device_accept_test_against_the_host_driven_step(mm, shipped):
     assert np.array_equal(ll2a, ll2)
     lib.sepaihrd_mh_destroy(mhA)
     lib.sepaihrd_mh_destroy(mhB)
+
+
+def test_kernel_info_says_whether_the_phase_pass_was_applied(mm, synth400):
+    """which build was measured.  Both arithmetic builds of the shipped library went through
+    csrc/phase_pass.py (the CPU suite asserts there is no fall-back marker); the fp32-state kernel does not use it."""
+    for arith in (mm.ARITH_FMA, mm.ARITH_STRICT):
+        hip = mm.HipObjective(synth400.with_(arith=arith))
+        for batch in (4096, 32768):
+            assert hip.kernel_info(batch)["phase_pass_applied"] == 1, (arith, batch)
+        hip.close()
+    hip = mm.HipObjective(synth400.with_(arith=mm.ARITH_FMA, precision=mm.PRECISION_F32))
+    assert hip.kernel_info(4096)["phase_pass_applied"] == 0
+    hip.close()
+
+
+def test_device_libm_selfcheck_and_the_fall_back_to_host_streams(mm, shipped, tmp_path, monkeypatch):
+    """ADVICE r3 (medium) / VERDICT r3 weak 6: the device's log / exp are restatements of THIS image's libm.  The sampler checks
+    that at run time (4096 fixed arguments, device against std::log / std::exp of the process) before it lets the device draw
+    the chains' streams.  Here: the check passes on this box; when it is made to fail (SEPAIHRD_LIBM_SELFCHECK=fail: the test
+    hook that stands for a host with another libm) the C entry points refuse, and the C++ sampler falls back to host-drawn
+    streams, says so, sets the flag -- and produces the same chains, because host streams ARE the reference's."""
+    import ctypes as C
+    pb = shipped.with_(arith=mm.ARITH_FMA, constraint_mode=mm.CONSTRAINT_REFLECT)
+    hip = mm.HipObjective(pb)
+    assert hip.device_libm_check() == (0, 0)
+    hip.close()
+    x0 = mm.draws.jitter_draws(pb, 1, 24)
+    kw = dict(adaptation_period=40, thinning=5, report_interval=100, checkpoint_chains=1)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    good = mm.HostObjective(pb).metropolis_hastings_reported(x0, 5, 300, 60, str(tmp_path / "a"), str(tmp_path / "a.log"), **kw)
+    assert not good["fell_back"] and good["failures"] == [0, 0, 0]
+    monkeypatch.setenv("SEPAIHRD_LIBM_SELFCHECK", "fail")
+    hip = mm.HipObjective(pb)
+    dl, de = hip.device_libm_check()
+    assert dl >= 1 and de >= 1
+    # the C ABI refuses to seed device streams on such a host
+    lib = mm.hipabi.load_library()
+    cfg = mm.hipabi.sepaihrd_mh_config(chains=4, iterations=10, thinning=1, adaptation_window=0, covariance_mode=0, reserved=0,
+                                       reg_eps=1e-6, scaling_factor=2.38 ** 2 / pb.n_params)
+    cov0 = np.ascontiguousarray(np.eye(pb.n_params) * 1e-4)
+    x4 = np.ascontiguousarray(x0[:4])
+    mh = lib.sepaihrd_mh_create(hip.ctx, C.byref(cfg), x4.ctypes.data, cov0.ctypes.data)
+    assert mh
+    assert lib.sepaihrd_mh_seed_streams(mh, 1) == -4            # SEPAIHRD_E_UNSUPPORTED
+    assert b"libm" in lib.sepaihrd_last_error(hip.ctx)
+    assert lib.sepaihrd_mh_keep_scale_on_device(mh, 1, C.c_double(0.234), 0) == -4
+    lib.sepaihrd_mh_destroy(mh)
+    hip.close()
+    fell = mm.HostObjective(pb).metropolis_hastings_reported(x0, 5, 300, 60, str(tmp_path / "b"), str(tmp_path / "b.log"), **kw)
+    assert fell["fell_back"]
+    assert "libm" in (tmp_path / "b.log").read_text().splitlines()[0] and (tmp_path / "b.log").read_text().startswith("WARNING")
+    assert np.array_equal(fell["samples"], good["samples"]) and np.array_equal(fell["sample_values"], good["sample_values"])
+    # and the files of the two runs are the same bytes: reports and checkpoints do not depend on where the streams are drawn
+    for name in ("posterior_trace_checkpoint.csv", "posterior_trace_final.csv", "posterior_trace.csv"):
+        assert (tmp_path / "a" / name).read_bytes() == (tmp_path / "b" / name).read_bytes(), name
+    strip = lambda text: [l for l in text.splitlines() if "libm" not in l]
+    assert strip((tmp_path / "a.log").read_text()) == strip((tmp_path / "b.log").read_text())
+
+
+def test_checkpoints_and_progress_lines_while_the_device_resident_sampler_runs(mm, shipped, tmp_path):
+    """VERDICT r3 missing 3 / next 5 (MetropolisHastingsSampler.cpp:363-383,399-411,440-469): every report_interval iterations
+    a progress line and posterior_trace_checkpoint.csv (the chain's last <= 5000 thinned samples), at the end
+    posterior_trace_final.csv and posterior_trace.csv -- from a run whose iterations are queued ahead of the device and which
+    does not stop for any of it.  A watcher thread reads the checkpoint file WHILE the run is going (nothing is killed): every
+    version it sees is a prefix of the final trace, line for line; header and number format are the reference's; the first
+    two chains report; the host-state loop writes the same bytes."""
+    import json
+    import threading
+    import time
+    pb = shipped.with_(arith=mm.ARITH_FMA, constraint_mode=mm.CONSTRAINT_REFLECT)
+    Cn, iters, thin, every = 512, 2400, 4, 200
+    x0 = mm.draws.jitter_draws(pb, 1, Cn)
+    out = tmp_path / "dev"
+    out.mkdir()
+    seen, stop = [], threading.Event()
+
+    def watch():
+        last = None
+        path = out / "posterior_trace_checkpoint.csv"
+        while not stop.is_set():
+            try:
+                st = path.stat()
+                key = (st.st_mtime_ns, st.st_size)
+                if key != last:
+                    seen.append((time.perf_counter(), path.read_text()))
+                    last = key
+            except FileNotFoundError:
+                pass
+            time.sleep(0.001)
+
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    host = mm.HostObjective(pb)
+    r = host.metropolis_hastings_reported(x0, 9, iters, 300, str(out), str(tmp_path / "dev.log"), adaptation_period=100, thinning=thin,
+                                          report_interval=every, checkpoint_chains=2)
+    t1 = time.perf_counter()
+    stop.set()
+    th.join()
+    assert not r["fell_back"] and r["failures"] == [0, 0, 0]
+    names = list(pb.param_names)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_output_headers.json")) as fh:
+        fmt = json.load(fh)["posterior_trace"]
+    final = (out / "posterior_trace_final.csv").read_text().splitlines()
+    assert final[0].split(",") == fmt["header"][:2] + names
+    n_s = 1 + (iters - 1) // thin
+    assert len(final) == 1 + n_s
+    for i in (0, 1, n_s - 1):    # iter as integer, every other field std::scientific << setprecision(6)
+        cells = final[1 + i].split(",")
+        assert cells[0] == str(i) and cells[1] == "%.6e" % r["sample_values"][0, i]
+        assert cells[2:] == ["%.6e" % v for v in r["samples"][0, i]]
+    assert (out / "posterior_trace.csv").read_text().splitlines() == final
+    # chain 1 reports too, under its own names
+    final1 = (out / "posterior_trace_final_chain1.csv").read_text().splitlines()
+    assert final1[1 + 7].split(",")[2:] == ["%.6e" % v for v in r["samples"][1, 7]]
+    # what the watcher saw while the run was going: several versions, each a prefix of the final trace
+    during = [(t, text) for t, text in seen if t < t1]
+    assert len(during) >= 3, (len(seen), t1 - t0)
+    sizes = []
+    for _, text in seen:
+        lines = text.splitlines()
+        assert lines[0] == final[0]
+        first = int(lines[1].split(",")[0])
+        assert lines[1:] == final[1 + first:1 + first + len(lines) - 1]
+        sizes.append(first + len(lines) - 1)
+    assert sizes == sorted(sizes) and sizes[-1] == (iters // every * every - 1) // thin + 1   # samples stored up to the last report
+    # the progress lines: one per report and chain, the reference's layout, values of THAT iteration
+    log = (tmp_path / "dev.log").read_text().splitlines()
+    lines0 = [l for l in log if l.startswith("INFO Iter:")]
+    lines1 = [l for l in log if l.startswith("INFO [chain 1] Iter:")]
+    assert len(lines0) == len(lines1) == iters // every
+    import re
+    pat = re.compile(r"INFO Iter: +(\d+) \| LogPost: (-?[\d.]+) \| Best: (-?[\d.]+) \| AccRate: ([\d.]+)% \| Scale: ([\d.]+)$")
+    for k, line in enumerate(lines0):
+        m = pat.match(line)
+        assert m and int(m.group(1)) == (k + 1) * every, line
+        t = (k + 1) * every - 1                                  # the iteration reported; its state is sample t / thin if stored
+        if t % thin == 0:
+            assert m.group(2) == "%.2f" % r["sample_values"][0, t // thin]
+        assert float(m.group(3)) >= float(m.group(2)) - 0.006
+    # the host-state loop (host libstdc++ streams, same chains) writes the same bytes
+    out2 = tmp_path / "host"
+    out2.mkdir()
+    r2 = host.metropolis_hastings_reported(x0[:3], 9, 420, 100, str(out2), str(tmp_path / "host.log"), adaptation_period=50, thinning=thin,
+                                           report_interval=100, checkpoint_chains=2, device_state=False)
+    out3 = tmp_path / "dev3"
+    out3.mkdir()
+    r3 = host.metropolis_hastings_reported(x0[:3], 9, 420, 100, str(out3), str(tmp_path / "dev3.log"), adaptation_period=50, thinning=thin,
+                                           report_interval=100, checkpoint_chains=2, device_state=True)
+    assert np.array_equal(r2["samples"], r3["samples"])
+    for name in ("posterior_trace_checkpoint.csv", "posterior_trace_final.csv", "posterior_trace.csv", "posterior_trace_checkpoint_chain1.csv"):
+        assert (out2 / name).read_bytes() == (out3 / name).read_bytes(), name
+    assert (tmp_path / "host.log").read_text() == (tmp_path / "dev3.log").read_text()

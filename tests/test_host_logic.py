@@ -532,3 +532,23 @@ def test_one_arithmetic_is_the_product_in_bench_adapter_and_docs(mm, monkeypatch
         text = open(os.path.join(root, doc)).read()
         assert "SEPAIHRD_ARITH=strict" in text, doc + " must name the opt-in"
         assert "r04_fma_vs_strict_100k.json" in text, doc + " must cite the run that settled the arithmetic"
+
+
+def test_libm_selfcheck_host_twin_and_its_arguments(mm):
+    """the device's log / exp restate ONE libm build; before a sampler lets the device draw the chains'
+    streams they are compared with the host's libm on fixed arguments (sepaihrd_device_libm_check).  This is the comparison
+    itself without a device: the same text compiled for the host, on the same arguments, against std::log / std::exp of
+    this process -- zero differences on this image -- and a look at what the arguments cover."""
+    r = mm.hostabi.libm_selfcheck()
+    assert r["n"] == 4096 and r["log_diff"] == 0 and r["exp_diff"] == 0
+    la, ea = r["log_args"], r["exp_args"]
+    assert np.all(la > 0) and np.all(np.isfinite(la))
+    near_one = np.abs(la - 1.0) < 0.0664
+    assert near_one.sum() >= 1000 and (la[near_one] > 1.0).sum() > 400 and (la[near_one] < 1.0).sum() > 400   # glibc's log1p-style branch, both sides
+    assert np.any((la > 1 - 2.0 ** -4 - 0.004) & (la < 1 - 2.0 ** -4)) or np.any(la < 0.94)                    # and arguments beyond its lower edge
+    assert (la < 1e-100).sum() > 100 and la.min() < 1e-290                                                      # tiny, the 2^k scaling of the table path
+    unit = (la > 0.0) & (la < 1.0) & ~near_one
+    assert unit.sum() > 1500                                                                                    # canonical uniforms / r2 of the polar method
+    assert ((ea >= -6.9) & (ea <= 2.3)).sum() >= 2048 and ea.min() < -35 and ea.max() > 35                      # log_scale_'s clamp range, and beyond
+    # the twin really is the device's function: it differs from libm where the restatement says it is not implemented
+    assert np.isnan(mm.hostabi.glibc_exp(np.array([600.0]))[0])
