@@ -36,10 +36,12 @@ PARITY_NOTES = {
     "strict": "no contraction, IEEE division, the CPU build's operation sequence: step counts identical to the oracle "
               "for every chain of this batch, states <= 1e-9, MH accept traces bit-identical "
               "(test_headline_batch_matches_oracle_chain_by_chain, test_multichain_mh_matches_oracle_sampler)",
-    "fma": "contraction + folded constants + hardware log2/exp2 in the step-size factor: states <= 1e-6 (north-star "
-           "tolerance; measured 1e-11), log-likelihood <= 1e-7; MH accept traces equal to the strict oracle's for the "
-           "tested seeds (4096 chains x 300 iterations: test_headline_batch_accept_traces_in_production_arithmetic; this "
-           "run's own count: sampler_pipeline.accept_trace_mismatches_vs_strict) but not guaranteed bit-exact",
+    "fma": "the product arithmetic (default of bench.py AND of the drop-in constructors; SEPAIHRD_ARITH=strict opts out): "
+           "contraction + folded constants + hardware log2/exp2 in the step-size factor: states <= 1e-6 (north-star "
+           "tolerance; measured 1e-11), log-likelihood <= 1e-7; MH accept decisions: 0 of 409 595 904 differ from strict over "
+           "4096 chains x the reference's 100 000 iterations (profiles/r04_fma_vs_strict_100k.json), 0 of 1.2 M against the strict "
+           "ORACLE (test_headline_batch_accept_traces_in_production_arithmetic), this run's own count in "
+           "sampler_pipeline.accept_trace_mismatches_vs_strict -- measured, not proven",
 }
 
 
@@ -61,6 +63,9 @@ def parse_args():
                          "of BASELINE configs[4]'s sweep (fp64 likelihood), 3..16 age classes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--allgather", action="store_true", help="time the RCCL all-gather of chain summaries")
+    ap.add_argument("--other-workloads", type=int, default=1,
+                    help="1 (default, with --workload c1 on one GPU): a few steps of every other BASELINE config after the timed region "
+                         "(other_workloads in the line; about 25 s, most of it generating their draws); 0 = skip")
     ap.add_argument("--sampler-iterations", type=int, default=400,
                     help="informational Adaptive-Metropolis run around the kernel after the timed region (0 = skip)")
     ap.add_argument("--sampler-long-iterations", type=int, default=100000,
@@ -161,8 +166,8 @@ def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=
     """Informational, outside the timed region: the whole Adaptive-Metropolis iteration around the kernel
     (random streams, proposal / adaptation state, accept test and scale adaptation all on the device, one evaluation per
     chain and iteration; the host queues iterations), proposals per second for the step's chains.
-      * a short run (`iterations`): the iteration loop as the host library times it, MEDIAN of three runs, the better of
-        one and two chain groups; the same run in strict arithmetic gives accept_trace_mismatches_vs_strict -- the
+      * a short run (`iterations`): the iteration loop as the host library times it, MEDIAN of three runs, ONE chain group (the default; two
+        groups are timed beside it); the same run in strict arithmetic gives accept_trace_mismatches_vs_strict -- the
         acceptance contract of the arithmetic `value` is measured in, counted on this run's own chains;
       * a run at the reference's own settings (`long_iterations`, burn-in 5 000, adaptation_period 100, thinning 100):
         the covariance refresh is O(P^2) from running co-moments, so the iteration must not slow down as the chain
@@ -195,14 +200,16 @@ def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=
         s1, dt1, r1 = median_of_three(run_one)
         s2, dt2, r2 = median_of_three(run_two)
         same = bool(np.array_equal(r1["accept_trace"], r2["accept_trace"]))
-        steady, dt, r, groups = (s2, dt2, r2, 2) if s2 < s1 else (s1, dt1, r1, 1)
+        # ONE chain group is what the sampler runs by default and what this line reports; two groups (two contexts, streams and
+        # host threads) beside it for information (no "better of")
+        steady, dt, r, groups = s1, dt1, r1, 1
         out = {"proposals_per_s": theta.shape[0] / steady, "ms_per_iteration": steady * 1e3, "chain_groups": groups,
                "ms_per_iteration_by_groups": {"1": s1 * 1e3, "2": s2 * 1e3}, "groups_give_identical_accept_traces": same,
                "ms_per_iteration_incl_setup": dt / (iters - 1) * 1e3, "setup_and_readback_ms": max(0.0, (dt - steady * (iters - 1)) * 1e3),
                "chains": int(theta.shape[0]), "iterations": iters, "covariance_refreshes_in_run": int(sum(1 for t in range(kw["burn_in"] + 1, iters) if t % kw["adaptation_period"] == 0)),
                "acceptance": float(r["accepted"].mean() / (iters - 1)),
                "note": "ms_per_iteration = the iteration loop of a %d-iteration run timed inside the host library (median of three runs; the run's "
-                       "set-up and read-back are reported separately), the better of one and two chain groups; sampler state resident in HBM, "
+                       "set-up and read-back are reported separately), one chain group; sampler state resident in HBM, "
                        "as are the chains' mt19937 streams, the accept test and the scale adaptation: the host only queues iterations (DESIGN.md 6c)" % iters}
         if pb.arith == mm.ARITH_FMA:
             strict = mm.HostObjective(pb.with_(arith=mm.ARITH_STRICT)).metropolis_hastings(theta, 1, iters, device_state=True, **kw)
@@ -225,9 +232,105 @@ def sampler_pipeline(mm, pb, theta, iterations=None, long_iterations=0, step_ms=
                                "acceptance": float(rl["accepted"].mean() / (n - 1)),
                                "note": "the reference's own run length (data/configuration/mcmc_settings.txt); covariance refresh from "
                                        "running co-moments, O(P^2) per refresh whatever the chain length; one chain group"}
+            try:  # the acceptance contract at THIS run length: fma against strict, same seeds (replayed from the committed run)
+                with open(os.path.join(ROOT, "profiles", "r04_fma_vs_strict_100k.json")) as fh:
+                    fv = json.load(fh)
+                out["long_run"]["accept_trace_mismatches_vs_strict"] = {
+                    "chains_with_a_flip": fv["chains_with_a_flip"], "decisions_compared": fv["decisions_compared_on_identical_chains"],
+                    "chains": fv["chains"], "iterations": fv["iterations"],
+                    "source": "profiles/r04_fma_vs_strict_100k.json (tools/fma_vs_strict_100k.py: this workload, these settings, "
+                              "once in each arithmetic; replayed, NOT measured in this run -- the strict run takes 85 s)"}
+            except Exception:
+                pass
         return out
     except Exception as e:  # informational only
         return {"error": str(e)[:200]}
+
+
+OTHER_WORKLOADS = (("c2", "f64", 10), ("c3", "f64", 10), ("c5", "f64", 5), ("c5_f32", "f32", 5))
+
+
+def measure_other_workload(mm, torch, key, precision, steps, arith, dev, local_rank, golden_dir, traffic_table):
+    """One more BASELINE config in the driver's own line, after the timed region of the headline:
+    `steps` steps of the workload's own batch (configs[2] 65 536 chains Cash-Karp, configs[3]'s 32 768-chain per-GPU share,
+    configs[4] 16 ages x 1000 days in fp64 and with fp32 state), theta resident, two warm-up steps, HIP events on the stream
+    around the pass; then the SAME pass once more with events around every launch's integrator kernel and likelihood pass
+    (kernel_ms, and that pass's own step beside it so that kernel_ms <= its step holds by construction)."""
+    from mmid_amd import draws, workloads
+    name = key.split("_")[0]
+    pb = workloads.build(name, golden_dir, hip_factory=lambda q: mm.HipObjective(q, device=local_rank))
+    pb.arith = arith
+    pb.constraint_mode = mm.CONSTRAINT_REFLECT
+    pb.precision = mm.PRECISION_F32 if precision == "f32" else mm.PRECISION_F64
+    B = workloads.DEFAULT_CHAINS[name]
+    theta = torch.from_numpy(draws.jitter_draws(pb, 1, B)).to(dev)
+    d_ll = torch.empty(B, dtype=torch.float64, device=dev)
+    d_status = torch.empty(B, dtype=torch.int32, device=dev)
+    d_acc = torch.empty(B, dtype=torch.int32, device=dev)
+    d_rej = torch.empty(B, dtype=torch.int32, device=dev)
+    hip = mm.HipObjective(pb, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        hip.eval_batch_device(theta, d_ll, d_status=d_status, d_n_accept=d_acc, d_n_reject=d_rej, stream=stream.cuda_stream, B=B)
+
+    hip.reserve(B)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+
+    def timed_pass():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(steps):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3 / steps, e0.elapsed_time(e1) / steps
+
+    wall_ms, stream_ms = timed_pass()
+    hip.set_timing(1)
+    pass2_wall_ms, pass2_stream_ms = timed_pass()
+    tm = hip.get_timing()
+    hip.set_timing(False)
+    kernel_ms = tm["integrator_ms"] / max(tm["launches"], 1)
+    ll_ms = tm["likelihood_ms"] / max(tm["launches"], 1)
+    info = hip.kernel_info(B)
+    acc = d_acc.cpu().numpy().astype(np.float64)
+    rej = d_rej.cpu().numpy().astype(np.float64)
+    status = d_status.cpu().numpy()
+    flops_eval = algorithmic_flops_per_eval(pb.n, float(acc.mean()), pb.n_obs)
+    peak = FP64_VALU_PEAK_TFLOPS if precision == "f64" else 2 * FP64_VALU_PEAK_TFLOPS
+    solver_name = "dopri5" if pb.solver == mm.SOLVER_DOPRI5 else "cashkarp"
+    bytes_eval = 8 * pb.n_params + 16 + problem_bytes(pb) / B
+    split_ll = info.get("likelihood_form", 0) == 1 and precision == "f64"
+    tkey = f"{name}_{solver_name}_{('fma' if arith == mm.ARITH_FMA else 'strict') if precision == 'f64' else 'f32'}_B{B}"
+    out = {
+        "workload": f"BASELINE {name}: SEPAIHRD {pb.n} age groups, {solver_name}, {int(pb.times[-1] - pb.times[0])} days (T={pb.n_times}), "
+                    f"{B} chains/GPU, {'fp64' if precision == 'f64' else 'fp32 state, fp64 likelihood / time / theta'}",
+        "steps": steps, "ms_per_step": wall_ms, "step_ms_on_stream": stream_ms, "evals_per_s": B / (wall_ms * 1e-3),
+        "kernel": info["kernel_name"], "kernel_ms": kernel_ms, "likelihood_pass_ms": ll_ms,
+        "kernel_pass": {"ms_per_step": pass2_wall_ms, "step_ms_on_stream": pass2_stream_ms,
+                        "note": "the pass kernel_ms was measured in (events around every launch): kernel_ms + likelihood_pass_ms <= its own step"},
+        "likelihood_form": {0: "inline", 1: "separate pass over parked increments", 2: "consumer waves of the integrator's workgroup"}.get(info.get("likelihood_form", 0)),
+        "roofline": {"bound": "fp64_valu" if precision == "f64" else "fp32_valu", "peak": peak, "unit": "TFLOP/s",
+                     "achieved": flops_eval * B / (kernel_ms * 1e-3) / 1e12, "frac": flops_eval * B / (kernel_ms * 1e-3) / 1e12 / peak,
+                     "frac_of_step": flops_eval * B / (wall_ms * 1e-3) / 1e12 / peak, "algorithmic_flops_per_eval": flops_eval,
+                     "hbm_algorithmic_bytes_per_eval": bytes_eval,
+                     "hbm_workspace_bytes_per_eval": pb.n_times * 3 * pb.n * 8 if split_ll else 0,
+                     "hbm_frac_algorithmic": bytes_eval * B / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": traffic_table.get(tkey, {}).get("hbm_bytes_per_launch"),
+                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, replayed)" if tkey in traffic_table else None},
+        "kernel_info": {k: info[k] for k in ("lanes_per_chain", "chains_per_wave", "vgprs", "lds_bytes", "scratch_bytes", "max_blocks_per_cu",
+                                             "phase_pass_applied")},
+        "steps_per_eval": {"accepted_mean": float(acc.mean()), "rejected_mean": float(rej.mean()), "attempts_max": float((acc + rej).max())},
+        "status_counts": np.bincount(status, minlength=5).tolist(),
+    }
+    hip.close()
+    del theta, d_ll, d_status, d_acc, d_rej
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -322,9 +425,13 @@ def main():
     # stream time per launch, which is why they are not in the timed pass: the kernel time is what they bracket, not
     # what they cost).  roofline.achieved divides by this; roofline.frac_of_step divides by ms_per_step instead.
     hip.set_timing(1)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record(stream)
     for i in range(K):
         step(i)
+    k1.record(stream)
     torch.cuda.synchronize(dev)
+    kernel_pass_step_ms = k0.elapsed_time(k1) / max(K, 1)   # that pass's OWN step: kernel_ms is part of it by construction
     tm = hip.get_timing()
     hip.set_timing(False)
     kernel_ms = tm["integrator_ms"] / max(tm["launches"], 1)      # dominant kernel: sepaihrd_eval_kernel
@@ -445,6 +552,10 @@ def main():
                                    if traffic is not None else None),
                 "kernel": info["kernel_name"], "kernel_ms": kernel_ms, "likelihood_pass_ms": ll_pass_ms,
                 "step_ms_on_stream": step_ms,
+                # the pass kernel_ms comes from, timed as a whole on the same stream: kernel_ms <= kernel_pass_step_ms always;
+                # against ms_per_step of the timed pass (no event records between its launches) it can read either way by the
+                # box's clock of the moment
+                "kernel_pass_step_ms": kernel_pass_step_ms,
                 "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_eval": bytes_eval,
@@ -455,7 +566,7 @@ def main():
             },
             "kernel_info": {k: info[k] for k in ("lanes_per_chain", "chains_per_wave", "vgprs", "lds_bytes",
                                                  "scratch_bytes", "max_blocks_per_cu", "num_cus",
-                                                 "device_name")},
+                                                 "device_name", "phase_pass_applied")},
             "steps_per_eval": {"accepted_mean": float(acc.mean()), "rejected_mean": float(rej.mean()),
                                "attempts_max": float((acc + rej).max())},
             "status_counts": np.bincount(status, minlength=4).tolist(),
@@ -471,6 +582,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pb, pools_host[0], args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        out["other_workloads"] = None
+        if world == 1 and args.workload == "c1" and args.other_workloads and args.precision == "f64":
+            tt = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                    tt = json.load(fh)
+            except Exception:
+                pass
+            out["other_workloads"] = {}
+            for key, precision, steps in OTHER_WORKLOADS:
+                try:
+                    out["other_workloads"][key] = measure_other_workload(mm, torch, key, precision, steps, pb.arith, dev, local_rank,
+                                                                         os.path.join(ROOT, "tests", "golden"), tt)
+                except Exception as e:  # informational: never costs the headline its line
+                    out["other_workloads"][key] = {"error": str(e)[:200]}
         out["sampler_pipeline"] = (sampler_pipeline(mm, pb, pools_host[0], args.sampler_iterations,
                                                     args.sampler_long_iterations if args.workload == "c1" else 0, out["ms_per_step"])
                                    if world == 1 and args.sampler_iterations > 1 else None)

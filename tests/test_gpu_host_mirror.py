@@ -967,4 +967,4 @@ def test_checkpoints_and_progress_lines_while_the_device_resident_sampler_runs(m
     assert np.array_equal(r2["samples"], r3["samples"])
     for name in ("posterior_trace_checkpoint.csv", "posterior_trace_final.csv", "posterior_trace.csv", "posterior_trace_checkpoint_chain1.csv"):
         assert (out2 / name).read_bytes() == (out3 / name).read_bytes(), name
-    assert (tmp_path / "host.log").read_text() == (tmp_path / "dev3.log").read_text()
+    assert (tmp_path / "host.log").read_text().replace(str(out2), "<dir>") == (tmp_path / "dev3.log").read_text().replace(str(out3), "<dir>")
