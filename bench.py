@@ -254,7 +254,7 @@ def measure_other_workload(mm, torch, key, precision, steps, arith, dev, local_r
     """One more BASELINE config in the driver's own line, after the timed region of the headline:
     `steps` steps of the workload's own batch (configs[2] 65 536 chains Cash-Karp, configs[3]'s 32 768-chain per-GPU share,
     configs[4] 16 ages x 1000 days in fp64 and with fp32 state), theta resident, two warm-up steps, HIP events on the stream
-    around the pass; then the SAME pass once more with events around every launch's integrator kernel and likelihood pass
+    around the pass (after the same quarter-second pre-warm as the headline); then the SAME pass once more with events around every launch's integrator kernel and likelihood pass
     (kernel_ms, and that pass's own step beside it so that kernel_ms <= its step holds by construction)."""
     from mmid_amd import draws, workloads
     name = key.split("_")[0]
@@ -275,9 +275,13 @@ def measure_other_workload(mm, torch, key, precision, steps, arith, dev, local_r
         hip.eval_batch_device(theta, d_ll, d_status=d_status, d_n_accept=d_acc, d_n_reject=d_rej, stream=stream.cuda_stream, B=B)
 
     hip.reserve(B)
-    for _ in range(2):
+    # the same untimed pre-warm as the headline (PRE_WARM_SECONDS of the step, at least two): a context's first launches run
+    # 4-8 % slow (measured: c3 2.17 ms in the first ten steps, 1.99 in the next ten)
+    t_pre, n_pre = time.perf_counter(), 0
+    while n_pre < 2 or time.perf_counter() - t_pre < PRE_WARM_SECONDS:
         step()
-    torch.cuda.synchronize(dev)
+        n_pre += 1
+        torch.cuda.synchronize(dev)
 
     def timed_pass():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

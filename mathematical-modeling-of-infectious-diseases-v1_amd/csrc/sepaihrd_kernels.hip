@@ -159,7 +159,7 @@ __device__ __forceinline__ void rhs(const LaneModel<LPC>& q, const double (&x)[N
     dx[5] = fma(-q.get(MF_R_H), H, flow_IH);
     dx[6] = fma(-q.get(MF_R_ICU), ICU, flow_H_ICU);
     dx[7] = fma(q.get(MF_GAMMA_ICU), ICU, fma(q.get(MF_GAMMA_A), A, fma(q.get(MF_GAMMA_H), H, q.get(MF_GAMMA_I) * I)));
-    dx[8] = fma(q.get(MF_D_H), H, fma(q.get(MF_D_COMM), I, q.get(MF_D_ICU) * ICU));
+    dx[8] = fma(q.get(MF_D_ICU), ICU, fma(q.get(MF_D_COMM), I, q.get(MF_D_H) * H));  // H, I, ICU: the order the 16-lane form's slot-2 stream visits them in
     dx[9] = flow_IH;
     dx[10] = flow_H_ICU;
 #else
@@ -379,7 +379,10 @@ __device__ __forceinline__ void rk_stages_row_coef(const double cur, const doubl
 // WPS = waves per SIMD the register allocation is budgeted for.  1 (up to 512 unified VGPRs) is the
 // default; the Cash-Karp stepper (no FSAL derivative, fewer live stage vectors) also gets a 2-wave
 // build, launched when the batch is large enough to put two waves on every SIMD: measured +13..22 %
-// there, while the Dopri5 body loses at 2 waves/SIMD (its spills go to scratch).
+// there, while the 4-age Dopri5 body loses at 2 waves/SIMD with the logs inline (its spills go to scratch; it reaches
+// two waves the other way, with the likelihood as a separate pass).  Round 4: the SIXTEEN-age Dopri5 integrator of the
+// tolerance build takes the 2-wave budget as well -- measured in one box on configs[4] (tools/ab.sh): 17.92 -> 17.01 ms
+// per 32 768-chain step (+5.3 %) although 40 registers go to scratch.
 // INLINE_LL selects where the Poisson terms are evaluated:
 //   false  the integrator parks the daily increments of D, CumH, CumICU in HBM and a separate pass,
 //          parallel over (chain, day, age), evaluates the likelihood -- best while the batch does not
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     q.set(MF_R_I, q.get(MF_GAMMA_I) + q.get(MF_H) + q.get(MF_D_COMM));
     q.set(MF_R_H, q.get(MF_GAMMA_H) + q.get(MF_D_H) + q.get(MF_ICU));
     q.set(MF_R_ICU, q.get(MF_GAMMA_ICU) + q.get(MF_D_ICU));
-    q.set(MF_PG, q.get(MF_P) * q.get(MF_GAMMA_P));
+    q.set(MF_PG, rounded_here(q.get(MF_P) * q.get(MF_GAMMA_P)));
     q.set(MF_PI, q.get(MF_GAMMA_P) - q.get(MF_PG));
     // column j of the contact row also carries age class j's h_infec / N: (a_i M(i,j)) * c_j, so that the pressure
     // P + A + theta I needs no scaling of its own in the RHS (one multiplication fewer per call, in every form)
@@ -970,61 +973,93 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     }
 }
 
-// Likelihood pass for saturating batches: one lane per (chain, stream) walks the days and, within a day, the
-// ages -- the reference's two nested serial sums -- so there is no cross-lane traffic and no rows[] round trip;
-// the increments of all ages of a chain arrive in one vector load, the observations are wave-uniform
-// (scalar loads).  Needs >= 1536 waves of (chain, stream) lanes to pay (below that the (chain, day, age)-parallel
-// kernel above is faster); same operations in the same order, so the same bits.  The stream's sum goes to
-// rows[0][stream][chain] and the reduce kernel finishes with n_rows = 1.
-template <int LPC>
+// Likelihood pass for saturating batches: PARTS adjacent lanes per (chain, stream) walk the days and, within a day, the
+// ages -- the reference's two nested serial sums -- so there is no rows[] round trip; the increments of a lane's ages
+// arrive in one vector load, the observations are wave-uniform (scalar loads).  Same operations in the same order as the
+// (chain, day, age)-parallel kernel above, so the same bits: a day's row sum is ((t_0 + t_1) + t_2) + ... with the partial sum
+// handed from lane to lane (part p adds its ages onto what part p - 1 hands over, one DPP move per hand-over), and the LAST part
+// adds the rows in day order.  The stream's sum goes to rows[0][stream][chain] and the reduce kernel finishes with n_rows = 1.
+// PARTS is a matter of balance, not of arithmetic: with one lane per (chain, stream) a 32 768-chain batch is 1536 waves on
+// 1024 SIMDs -- half of them hold two waves, half one, and the kernel takes as long as the SIMDs with two (round 4: 0.377 ms,
+// of which ~0.1 ms is that imbalance); two lanes per (chain, stream) make it 3072 waves, three on every SIMD.
+template <int LPC, int PARTS>
 __global__ __launch_bounds__(WAVE) void sepaihrd_ll_serial_kernel(const DevProblem pb, const int B, const EvalOutputs out,
                                                                    const int cum_chains) {
-    const int chain = blockIdx.x * WAVE + threadIdx.x;
+    static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "a (chain, stream) is one lane, a pair or a quad");
+    static_assert(LPC % PARTS == 0, "every part takes the same number of ages");
+    constexpr int AGES = LPC / PARTS;                  // ages per lane
+    const int t = blockIdx.x * WAVE + threadIdx.x;
+    const int chain = t / PARTS, part = t % PARTS;
     const int s = blockIdx.y;  // stream: H, ICU, D
     const bool valid = chain < B;
     const size_t c = valid ? (size_t)chain : 0;
     const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU
     const size_t stride = (size_t)cum_chains * LPC;
-    const double* cur = out.cum + (size_t)comp * stride + c * LPC;
+    const double* cur = out.cum + (size_t)comp * stride + c * LPC + part * AGES;
     double acc = 0.0;
     // the sums are a dependent chain, the loads are not: DAYS days of increments are requested at a time
-    constexpr int DAYS = (LPC <= 4) ? 8 : (LPC == 8 ? 4 : 2);
+    constexpr int DAYS = (AGES <= 4) ? 8 : (AGES == 8 ? 4 : 2);
     for (int k0 = pb.runup_offset; k0 < pb.T; k0 += DAYS) {
-        double inc[DAYS][LPC];
+        double inc[DAYS][AGES];
         SEP_UNROLL
         for (int d = 0; d < DAYS; ++d) {
             const int k = (k0 + d < pb.T) ? k0 + d : pb.T - 1;
             const double* row = cur + (size_t)k * 3 * stride;
-            if constexpr (LPC % 4 == 0) {
+            if constexpr (AGES % 4 == 0) {
                 SEP_UNROLL
-                for (int a = 0; a < LPC; a += 4) {
+                for (int a = 0; a < AGES; a += 4) {
                     const double4 v = *reinterpret_cast<const double4*>(row + a);
                     inc[d][a] = v.x; inc[d][a + 1] = v.y; inc[d][a + 2] = v.z; inc[d][a + 3] = v.w;
                 }
+            } else if constexpr (AGES % 2 == 0) {
+                SEP_UNROLL
+                for (int a = 0; a < AGES; a += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(row + a);
+                    inc[d][a] = v.x; inc[d][a + 1] = v.y;
+                }
             } else {
                 SEP_UNROLL
-                for (int a = 0; a < LPC; ++a) inc[d][a] = row[a];
+                for (int a = 0; a < AGES; ++a) inc[d][a] = row[a];
             }
         }
         SEP_UNROLL
         for (int d = 0; d < DAYS; ++d) {
             const int k = k0 + d;
             if (k >= pb.T) break;
-            const double* rec = pb.grid + (size_t)k * LPC * 4 + s;  // obs of age a at rec[4 a]: uniform over the wave
-            double r = 0.0;
+            const double* rec = pb.grid + ((size_t)k * LPC + part * AGES) * 4 + s;  // obs of the lane's a-th age at rec[4 a]
+            double tv[AGES];
             SEP_UNROLL
-            for (int a = 0; a < LPC; ++a) {
+            for (int a = 0; a < AGES; ++a) {
                 const double x = (inc[d][a] < 0.0) ? 0.0 : inc[d][a];  // cwiseMax(0.0)
                 const double obs = rec[4 * a];
                 const double sim = x + 1e-10;
                 const double v = obs * log_pos(sim) - sim;
-                const double tv = (obs >= 0.0 && isfinite(obs)) ? v : 0.0;
-                r = (a == 0) ? tv : r + tv;  // "0.0 +" dropped: value-identical
+                tv[a] = (obs >= 0.0 && isfinite(obs)) ? v : 0.0;
             }
-            acc += r;
+            // ages ascending across the parts: part 0 starts the sum ("0.0 +" dropped: value-identical), every later part
+            // continues the one its left neighbour hands over
+            double r = tv[0];
+            if constexpr (PARTS == 1) {
+                SEP_UNROLL
+                for (int a = 1; a < AGES; ++a) r += tv[a];
+            } else {
+                SEP_UNROLL
+                for (int a = 1; a < AGES; ++a) r += tv[a];          // part 0's own ages (the others redo theirs below)
+                SEP_UNROLL
+                for (int p = 1; p < PARTS; ++p) {
+                    // lane of part p takes the running sum of part p - 1 (quad_perm: every lane reads its left neighbour)
+                    const double left = dpp_move<0x90>(r);           // quad_perm:[0,0,1,2]
+                    if (part == p) {
+                        r = left + tv[0];
+                        SEP_UNROLL
+                        for (int a = 1; a < AGES; ++a) r += tv[a];
+                    }
+                }
+            }
+            acc += r;  // meaningful in the last part's lane
         }
     }
-    if (valid) out.rows[(size_t)s * cum_chains + chain] = acc;
+    if (valid && part == PARTS - 1) out.rows[(size_t)s * cum_chains + chain] = acc;
 }
 
 // Likelihood pass 2: one lane per (chain, stream) adds the daily row sums in day order (the serial
@@ -1164,8 +1199,15 @@ int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, c
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), st);
     if constexpr (!INLINE_LL) {
         if ((B + WAVE - 1) / WAVE >= ll_serial_min_waves<LPC>() / 3) {
-            hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC>), dim3((B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out,
-                               cum_chains);
+            // lanes per (chain, stream): one from three waves per SIMD on; below that a pair, so that every SIMD holds the same
+            // number of waves (32 768 chains: 1536 waves -> 3072)
+            const int waves1 = 3 * ((B + WAVE - 1) / WAVE);
+            if (LPC % 2 == 0 && waves1 < 3 * 1024) {
+                if constexpr (LPC % 2 == 0)
+                    hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC, 2>), dim3((2 * B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+            } else {
+                hipLaunchKernelGGL((sepaihrd_ll_serial_kernel<LPC, 1>), dim3((B + WAVE - 1) / WAVE, 3), dim3(WAVE), 0, st, pb, B, out, cum_chains);
+            }
             hipLaunchKernelGGL(sepaihrd_ll_reduce_kernel, dim3((B + 15) / 16), dim3(WAVE), 0, st, pb, B, out, cum_chains, 1);
         } else {
             hipLaunchKernelGGL((sepaihrd_ll_terms_kernel<LPC>), dim3(blocks, (pb.T + LL_DAYS_PER_BLOCK - 1) / LL_DAYS_PER_BLOCK),
@@ -1211,7 +1253,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
     if (split_pays<LPC, SOLVER>((size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
-    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || LPC == 16))) {
         // two waves per SIMD only pay when there are two waves for every SIMD
         if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
     }
@@ -1255,7 +1297,7 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
     const size_t blocks = batch > 0 ? (size_t)((batch + CPW - 1) / CPW) : (size_t)1 << 20;
     if (split_pays<LPC, SOLVER>(blocks))
         return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name, LL_FORM_SEPARATE_PASS);
-    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && SEPAIHRD_DOPRI5_WPS2)) {
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || LPC == 16))) {
         if (blocks >= 2 * 1024) return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 2, true>, pb, LPC, info, name, LL_FORM_INLINE);
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, true>, pb, LPC, info, name, LL_FORM_INLINE);
