@@ -37,5 +37,35 @@ out = {"tag": tag, "per_launch_counter_averages": counters,
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     out["hbm_bytes_per_launch"] = {"fetch_reported": counters["FETCH_SIZE"] * 1024, "write": counters["WRITE_SIZE"] * 1024,
                                    "total_with_2x_fetch_correction": (2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024}
+# derived per-launch figures the documents quote
+c = counters
+if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
+    f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    out["derived"] = {"valu_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"], "salu_per_wave": c.get("SQ_INSTS_SALU", 0.0) / c["SQ_WAVES"],
+                      "fp64_share_of_valu": f64 / c["SQ_INSTS_VALU"] if f64 else None,
+                      # wave64 instruction counts x 64 lanes; an FMA is two flops
+                      "fp64_flops_issued": 64 * (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + 2 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0)) if f64 else None}
+    if bench and out["derived"]["fp64_flops_issued"]:
+        alg = bench["roofline"]["algorithmic_flops_per_eval"] * bench["config"]["chains_per_gpu"]
+        out["derived"]["fp64_flops_algorithmic"] = alg
+        out["derived"]["issued_over_algorithmic"] = out["derived"]["fp64_flops_issued"] / alg
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+# the replayed HBM traffic bench.py prints (roofline.traffic): profiles/pmc_traffic.json, one key per workload / solver / arithmetic / batch
+if bench and "hbm_bytes_per_launch" in out:
+    cfg = bench["config"]
+    wl = cfg["workload"].split()[1].rstrip(":")
+    solver = "cashkarp" if "cashkarp" in cfg["workload"] else "dopri5"
+    arith = "f32" if bench.get("dtype") == "f32" else cfg["arith"]
+    key = f"{wl}_{solver}_{arith}_B{cfg['chains_per_gpu']}"
+    path = "profiles/pmc_traffic.json"
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    alg = bench["roofline"]["hbm"]["algorithmic_bytes_per_eval"] * cfg["chains_per_gpu"]
+    ws = bench["roofline"]["hbm"]["likelihood_workspace_bytes_per_eval"] * cfg["chains_per_gpu"]
+    table[key] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"]["total_with_2x_fetch_correction"],
+                  "fetch_size_reported_bytes": out["hbm_bytes_per_launch"]["fetch_reported"], "write_size_bytes": out["hbm_bytes_per_launch"]["write"],
+                  "algorithmic_bytes_per_launch": alg, "over_algorithmic": out["hbm_bytes_per_launch"]["total_with_2x_fetch_correction"] / alg,
+                  "likelihood_workspace_bytes_per_launch": ws, "kernel": bench["roofline"]["kernel"],
+                  "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, per-launch average of the measured integrator kernel only)",
+                  "correction": "FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as reported"}
+    json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
