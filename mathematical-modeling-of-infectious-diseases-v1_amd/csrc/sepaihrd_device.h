@@ -158,7 +158,8 @@ constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate
 SEP_HOST_DEVICE inline int times_pad(const DevProblem& pb) { return (pb.T + 1) & ~1; }
 inline size_t eval_lds_bytes(const DevProblem& pb) {
     const int cpw = WAVE / pb.lpc;
-    return ((size_t)times_pad(pb) + LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P) *
+    // ... + 6 doubles per lane: the inline likelihood's state in the two-waves-per-SIMD builds (LL_IN_LDS, sepaihrd_kernels.hip)
+    return ((size_t)times_pad(pb) + LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P + 6 * WAVE) *
            sizeof(double);
 }
 

@@ -52,6 +52,9 @@
 #ifndef SEPAIHRD_DOPRI5_WPS2
 #define SEPAIHRD_DOPRI5_WPS2 0
 #endif
+#ifndef SEPAIHRD_LL_STATE_IN_LDS
+#define SEPAIHRD_LL_STATE_IN_LDS 1  // the inline likelihood's loop-carried state in LDS in the two-waves-per-SIMD builds (see LL_IN_LDS)
+#endif
 #ifndef SEPAIHRD_ARITH_FMA
 #error "compile with -DSEPAIHRD_ARITH_FMA=0 or 1"
 #endif
@@ -529,6 +532,13 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     double* const cum_lane = out.cum + (size_t)(chain0 + grp) * LPC + age;  // own column, shadow groups too
     double prevD = x[8], prevH = x[9], prevICU = x[10];  // row 0: X(0) - init_state = 0
     double llH = 0.0, llICU = 0.0, llD = 0.0;             // INLINE_LL accumulators
+    // Two-waves-per-SIMD builds of the tolerance arithmetic keep that state in LDS (LL_IN_LDS, round 4): with it the 4-age
+    // Dopri5 integrator fits 256 registers WITH its logs inline (253, nothing spilled; 273 without), so configs[3]'s batch no
+    // longer parks its increments in HBM (1.26 GB written and read back per 32 768-chain step): 1.92-2.00 -> 1.84 ms per step.
+    // Dopri5 only: the Cash-Karp integrator has the registers to spare (252) and LOSES 2.4 % when its observer goes through LDS
+    // (configs[2], same box: 3.015 -> 3.09 ms).
+    constexpr bool LL_IN_LDS = INLINE_LL && SEPAIHRD_LL_STATE_IN_LDS != 0 && SEPAIHRD_ARITH_FMA != 0 && WPS == 2 && SOLVER == 0;
+    double* const lds_ll = lds_theta + CPW * pb.P;  // [6][WAVE] behind the theta staging area (eval_lds_bytes budgets it)
 
     // INLINE_LL: grid record of output k for this lane, {obs_H, obs_ICU, obs_D, times[k+1]}, requested by
     // LDS-DMA (global_load_lds_dwordx4 x2: no VGPR destination) one whole RK step before it is read.
@@ -561,7 +571,13 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     };
     // inline form: all lanes execute, the terms of chains without do_it are discarded.  Records of
     // outputs before t = 0 and of padded ages carry NaN observations, which the Poisson term skips.
+    // LL_IN_LDS: the observer's loop-carried state (the three previous values, the three stream sums) lives in LDS between
+    // outputs instead of in twelve registers that are dead through the whole RK body; the theta staging area is free by then
     auto observe_inline = [&](bool do_it, int k, double oH, double oI, double oD) {
+        if constexpr (LL_IN_LDS) {
+            prevH = lds_ll[lane]; prevICU = lds_ll[WAVE + lane]; prevD = lds_ll[2 * WAVE + lane];
+            llH = lds_ll[3 * WAVE + lane]; llICU = lds_ll[4 * WAVE + lane]; llD = lds_ll[5 * WAVE + lane];
+        }
         double incH = x[9] - prevH, incICU = x[10] - prevICU, incD = x[8] - prevD;
         incH = (incH < 0.0) ? 0.0 : incH;  // cwiseMax(0.0)
         incICU = (incICU < 0.0) ? 0.0 : incICU;
@@ -585,6 +601,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         llH += row_sum(tH);
         llICU += row_sum(tI);
         llD += row_sum(tD);
+        if constexpr (LL_IN_LDS) {
+            lds_ll[lane] = prevH; lds_ll[WAVE + lane] = prevICU; lds_ll[2 * WAVE + lane] = prevD;
+            lds_ll[3 * WAVE + lane] = llH; lds_ll[4 * WAVE + lane] = llICU; lds_ll[5 * WAVE + lane] = llD;
+        }
         if (do_it) store_traj(k);
     };
 
@@ -599,6 +619,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     t_next = (T > 1) ? pb.times[1] : t;
     if constexpr (INLINE_LL) {
         const double oH = grid_lane[0], oI = grid_lane[1], oD = grid_lane[2];  // record 0 is read directly
+        if constexpr (LL_IN_LDS) {
+            lds_ll[lane] = prevH; lds_ll[WAVE + lane] = prevICU; lds_ll[2 * WAVE + lane] = prevD;
+            lds_ll[3 * WAVE + lane] = 0.0; lds_ll[4 * WAVE + lane] = 0.0; lds_ll[5 * WAVE + lane] = 0.0;
+        }
         observe_inline(active, 0, oH, oI, oD);
         if (active && T > 1) request_record(1);
     } else {
@@ -886,6 +910,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     // ---- 5. integrator status and step counters; the likelihood pass finishes the evaluation
     if (chain_valid && age == 0) {
         if constexpr (INLINE_LL) {  // total (SEPAIHRDObjectiveFunction.cpp:222-227)
+            if constexpr (LL_IN_LDS) { llH = lds_ll[3 * WAVE + lane]; llICU = lds_ll[4 * WAVE + lane]; llD = lds_ll[5 * WAVE + lane]; }
             double total = (llH + llICU) + llD;
             if (status == 0 && (isnan(total) || isinf(total))) status = 1;
             if (status != 0) total = -DBL_MAX;
@@ -1167,6 +1192,13 @@ inline int ll_serial_min_waves() {
 // Dopri5 in fma arithmetic with up to 4 age classes -- 15.1 M vs 13.9 M evals/s at 32 768 chains).  The 16-age
 // integrator needs 274 registers either way: parking bought it nothing and cost 12.6 GB written + read per 32 768-chain
 // step (22 % of the step in the pass that reads them back); it keeps its logs inline.
+// The Dopri5 integrator of the tolerance build takes the two-waves-per-SIMD register budget where that was MEASURED to pay
+// (tools/ab.sh, one box each): 4 lanes per chain with the likelihood's state in LDS (253 registers, nothing spilled: configs[3]
+// 1.92-2.00 -> 1.84 ms per step) and 16 lanes per chain (256 registers, 16 spilled: configs[4] +3-5 %).  Other lane counts keep
+// one wave per SIMD (8 lanes per chain would spill 31 registers; unmeasured).
+template <int LPC>
+constexpr bool dopri5_two_waves() { return SEPAIHRD_ARITH_FMA != 0 && ((LPC == 4 && SEPAIHRD_LL_STATE_IN_LDS != 0) || LPC == 16); }
+
 template <int LPC, int SOLVER>
 inline bool split_pays(size_t blocks) {
 #ifdef SEPAIHRD_EXPERIMENTS
@@ -1178,6 +1210,8 @@ inline bool split_pays(size_t blocks) {
 #endif
     if (blocks <= (size_t)SPLIT_LL_MAX_BLOCKS) return true;
     if (!(SEPAIHRD_ARITH_FMA != 0 && SOLVER == 0)) return false;
+    // from two waves per SIMD on the tolerance build's 4-age Dopri5 integrator keeps its logs inline at 256 registers (LL_IN_LDS)
+    if (dopri5_two_waves<LPC>() && blocks >= (size_t)2 * 1024) return false;
     static const bool second_wave = [] {
         hipFuncAttributes attr;
         return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>)) == hipSuccess &&
@@ -1253,7 +1287,7 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     // 1024 SIMDs: up to one wave per SIMD the chip is not full and the separate likelihood pass wins
     if (split_pays<LPC, SOLVER>((size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
-    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || LPC == 16))) {
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || dopri5_two_waves<LPC>()))) {
         // two waves per SIMD only pay when there are two waves for every SIMD
         if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
     }
@@ -1297,7 +1331,7 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
     const size_t blocks = batch > 0 ? (size_t)((batch + CPW - 1) / CPW) : (size_t)1 << 20;
     if (split_pays<LPC, SOLVER>(blocks))
         return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name, LL_FORM_SEPARATE_PASS);
-    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || LPC == 16))) {
+    if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || dopri5_two_waves<LPC>()))) {
         if (blocks >= 2 * 1024) return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 2, true>, pb, LPC, info, name, LL_FORM_INLINE);
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, true>, pb, LPC, info, name, LL_FORM_INLINE);
