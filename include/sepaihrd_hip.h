@@ -403,6 +403,10 @@ int sepaihrd_mh_seed_streams(sepaihrd_mh *mh, uint32_t seed0);
  * draws and scale adaptation on the host (MultiChainMetropolisHastings::deviceStreamsFellBack()).
  * Environment SEPAIHRD_LIBM_SELFCHECK=fail makes the check report a difference (test hook for that fall-back). */
 int sepaihrd_device_libm_check(sepaihrd_ctx *ctx, int32_t *n_log_diff, int32_t *n_exp_diff);
+/* The log of the Poisson term (SEPAIHRDObjectiveFunction.cpp:264-276 calls std::log) evaluated by the device on n host-resident
+ * arguments x > 0, normal numbers: the table path of glibc's log on the same constants -- std::log's bits outside
+ * [1 - 2^-4, 1 + 0x1.09p-4), within 1e-17 absolute inside.  Diagnostic for the parity tests; no evaluation path calls it. */
+int sepaihrd_device_log_values(sepaihrd_ctx *ctx, const double *x, int32_t n, double *out);
 int sepaihrd_mh_draw_first(sepaihrd_mh *mh);
 /* ... and the scalar scale adaptation: adaptGlobalScale (MetropolisHastingsSampler.cpp:104-152; log_scale_, the window of the
  * last 1000 accept flags, the emergency branches, global_scale_ = std::exp(log_scale_) with glibc's exp written out like its

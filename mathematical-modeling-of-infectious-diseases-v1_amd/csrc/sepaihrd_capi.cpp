@@ -875,7 +875,7 @@ int sepaihrd_get_kernel_info_for_batch(sepaihrd_ctx* ctx, int32_t batch_chains, 
     info->chains_per_wave = WAVE / li.lanes_per_chain;
     info->block_threads = WAVE;
     info->vgprs = li.vgprs; info->sgprs = li.sgprs; info->scratch_bytes = li.scratch;
-    info->lds_bytes = li.lds_static + (int)eval_lds_bytes(ctx->dp);
+    info->lds_bytes = li.lds_static + li.lds_dynamic;
     info->max_blocks_per_cu = li.max_blocks_per_cu;
     info->likelihood_form = li.likelihood_form;
     info->phase_pass_applied = ctx->precision == SEPAIHRD_PRECISION_F32 ? 0  // the fp32-state kernel does not go through the pass
@@ -1360,6 +1360,20 @@ int sepaihrd_device_libm_check(sepaihrd_ctx* ctx, int32_t* n_log_diff, int32_t* 
     }
     if (n_log_diff) *n_log_diff = ctx->libm_log_diff;
     if (n_exp_diff) *n_exp_diff = ctx->libm_exp_diff;
+    return SEPAIHRD_OK;
+}
+
+int sepaihrd_device_log_values(sepaihrd_ctx* ctx, const double* x, int32_t n, double* out) {
+    if (!ctx || n < 0 || (n > 0 && (!x || !out))) return SEPAIHRD_E_INVALID_ARG;
+    if (n == 0) return SEPAIHRD_OK;
+    HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 2 * (size_t)n * sizeof(double)), ctx, return SEPAIHRD_E_HIP);
+    const bool ok = hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                    poisson_log_values(d, n, d + n, nullptr) == 0 &&
+                    hipMemcpy(out, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) { ctx->last_error = "device_log_values: launch or copy failed"; return SEPAIHRD_E_HIP; }
     return SEPAIHRD_OK;
 }
 

@@ -77,7 +77,7 @@ inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { retu
 // sepaihrd_kernel_info::likelihood_form (include/sepaihrd_hip.h: SEPAIHRD_LL_*)
 constexpr int LL_FORM_INLINE = 0, LL_FORM_SEPARATE_PASS = 1, LL_FORM_CONSUMER_WAVES = 2;
 struct LaunchInfo {
-    int vgprs, sgprs, lds_static, scratch, max_blocks_per_cu;
+    int vgprs, sgprs, lds_static, lds_dynamic, scratch, max_blocks_per_cu;
     int lanes_per_chain;  // of the kernel a launch of the given batch uses
     int likelihood_form;  // LL_FORM_*: inline in the integrator, separate pass over parked increments, consumer waves
     const char* name;
@@ -102,6 +102,8 @@ int kernel_info_fma(const DevProblem& pb, int solver, int batch, LaunchInfo* inf
 // 1 when the translation unit's device code went through csrc/phase_pass.py (csrc/Makefile), 0 for the plain compile
 int phase_pass_applied_strict();
 int phase_pass_applied_fma();
+// the Poisson term's log (csrc/sepaihrd_dev_common.inc log_pos) on n device-resident arguments
+int poisson_log_values(const double* d_x, int n, double* d_out, void* stream);
 
 // ---- posterior ensemble summaries (csrc/sepaihrd_ensemble.hip) ----
 constexpr int ENSEMBLE_MAX_SAMPLES = 16384;  // one sorted segment lives in LDS (128 KiB of 160 KiB)
@@ -156,10 +158,12 @@ constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate
 #define SEP_HOST_DEVICE
 #endif
 SEP_HOST_DEVICE inline int times_pad(const DevProblem& pb) { return (pb.T + 1) & ~1; }
-inline size_t eval_lds_bytes(const DevProblem& pb) {
+// dynamic LDS of one wave of sepaihrd_eval_kernel; inline_ll: the builds that evaluate the likelihood inside the integrator
+// keep no output grid in LDS (the next grid time rides in the observation record)
+inline size_t eval_lds_bytes(const DevProblem& pb, bool inline_ll = false) {
     const int cpw = WAVE / pb.lpc;
     // ... + 6 doubles per lane: the inline likelihood's state in the two-waves-per-SIMD builds (LL_IN_LDS, sepaihrd_kernels.hip)
-    return ((size_t)times_pad(pb) + LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P + 6 * WAVE) *
+    return ((size_t)(inline_ll ? 0 : times_pad(pb)) + LDS_REC_DOUBLES + pb.nm_pad + (size_t)cpw * (pb.nm + 1) + (size_t)cpw * pb.P + 6 * WAVE) *
            sizeof(double);
 }
 

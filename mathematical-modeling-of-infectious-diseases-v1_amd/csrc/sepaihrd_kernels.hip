@@ -251,7 +251,7 @@ __device__ __forceinline__ double pow_ctl(double x, double c) {
     const float l2 = __builtin_amdgcn_logf((float)x);
     return (double)__builtin_amdgcn_exp2f((float)c * l2);
 #else
-    return exp_ctl(c * log_pos(x));
+    return exp_ctl(c * log_ctl(x));
 #endif
 }
 
@@ -399,8 +399,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
                                                               const int cum_chains) {
     constexpr int CPW = WAVE / LPC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* const lds_times = lds;                     // [T] output grid
-    double* const lds_rec = lds + times_pad(pb);       // [2][64 lanes][2]  LDS-DMA landing zone (INLINE_LL)
+    // the inline-likelihood builds take the next grid time from the observation record: no output grid in their LDS (it was
+    // 8 KB per wave at 1001 days -- with 2 KB more for the log table a CU held 7 waves of the 16-age kernel instead of 8)
+    double* const lds_times = lds;                     // [T] output grid (separate-pass builds only)
+    double* const lds_rec = lds + (INLINE_LL ? 0 : times_pad(pb));  // [2][64 lanes][2]  LDS-DMA landing zone (INLINE_LL)
     double* const lds_mends = lds_rec + LDS_REC_DOUBLES;  // [nm_pad]
     double* const lds_bk = lds_mends + pb.nm_pad;      // [CPW][nm + 1]
     double* const lds_theta = lds_bk + CPW * (pb.nm + 1);
@@ -427,7 +429,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         }
     }
     for (int k = lane; k < pb.nm_pad; k += WAVE) lds_mends[k] = pb.mends[k];
-    for (int k = lane; k < pb.T; k += WAVE) lds_times[k] = pb.times[k];
+    if constexpr (!INLINE_LL) {
+        for (int k = lane; k < pb.T; k += WAVE) lds_times[k] = pb.times[k];
+    }
+    if constexpr (INLINE_LL) stage_log_table(lane, WAVE);  // the Poisson term's log reads its table from LDS
     __syncthreads();
     const double* th = lds_theta + g * P;
 
@@ -585,12 +590,14 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
         prevH = do_it ? x[9] : prevH;
         prevICU = do_it ? x[10] : prevICU;
         prevD = do_it ? x[8] : prevD;
-        auto term = [&](double obs, double sim) -> double {
-            sim += 1e-10;
-            const double v = obs * log_pos(sim) - sim;
+        const double sim[3] = {incH + 1e-10, incICU + 1e-10, incD + 1e-10};
+        double lg[3];
+        log_pos3(sim, lg);
+        auto term = [&](double obs, int s) -> double {
+            const double v = obs * lg[s] - sim[s];
             return (do_it && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
         };
-        const double tH = term(oH, incH), tI = term(oI, incICU), tD = term(oD, incD);
+        const double tH = term(oH, 0), tI = term(oI, 1), tD = term(oD, 2);
         auto row_sum = [&](double tv) -> double {  // ages ascending: calculateSingleLogLikelihood's inner loop
             double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
             [&]<int... J>(std::integer_sequence<int, J...>) {
@@ -957,6 +964,8 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     const int lane = threadIdx.x % WAVE;
     const size_t col = (size_t)blockIdx.x * WAVE + lane;  // chain * LPC + age
     const int k = blockIdx.y * LL_DAYS_PER_BLOCK + threadIdx.x / WAVE;
+    stage_log_table(threadIdx.x, WAVE * LL_DAYS_PER_BLOCK);
+    __syncthreads();
     if (k >= pb.T) return;
     const size_t stride = (size_t)cum_chains * LPC;
     const size_t chain = col / LPC;
@@ -1013,6 +1022,8 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_serial_kernel(const DevProbl
     static_assert(PARTS == 1 || PARTS == 2 || PARTS == 4, "a (chain, stream) is one lane, a pair or a quad");
     static_assert(LPC % PARTS == 0, "every part takes the same number of ages");
     constexpr int AGES = LPC / PARTS;                  // ages per lane
+    stage_log_table(threadIdx.x, WAVE);
+    __syncthreads();
     const int t = blockIdx.x * WAVE + threadIdx.x;
     const int chain = t / PARTS, part = t % PARTS;
     const int s = blockIdx.y;  // stream: H, ICU, D
@@ -1222,7 +1233,7 @@ inline bool split_pays(size_t blocks) {
 
 template <int LPC, int SOLVER, int WPS, bool INLINE_LL>
 int launch_wps(const DevProblem& pb, const double* d_theta, int blocks, int B, const EvalOutputs& out, void* stream) {
-    const size_t lds = eval_lds_bytes(pb);
+    const size_t lds = eval_lds_bytes(pb, INLINE_LL);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int cum_chains = blocks * (WAVE / LPC);  // columns incl. the shadow groups of the last wave
     if constexpr (!INLINE_LL) {
@@ -1305,7 +1316,9 @@ int info_of(K kernel, const DevProblem& pb, int lanes, LaunchInfo* info, const c
     info->lds_static = (int)attr.sharedSizeBytes;
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds_bytes ? lds_bytes : eval_lds_bytes(pb)) != hipSuccess) nb = -1;
+    if (lds_bytes == 0) lds_bytes = eval_lds_bytes(pb, ll_form == LL_FORM_INLINE);
+    info->lds_dynamic = (int)lds_bytes;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds_bytes) != hipSuccess) nb = -1;
     info->max_blocks_per_cu = nb;
     info->lanes_per_chain = lanes;
     info->name = name;
@@ -1336,6 +1349,17 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, true>, pb, LPC, info, name, LL_FORM_INLINE);
 }
+
+#if SEPAIHRD_ARITH_FMA
+// the Poisson term's log on caller-given arguments (sepaihrd_device_log_values: the tests compare it with the host's std::log;
+// one copy, in the tolerance build's translation unit -- log_pos() is the same explicit operation sequence in both builds)
+__global__ __launch_bounds__(WAVE) void log_values_kernel(const double* __restrict__ x, const int n, double* __restrict__ out) {
+    stage_log_table(threadIdx.x, WAVE);
+    __syncthreads();
+    const int i = blockIdx.x * WAVE + threadIdx.x;
+    if (i < n) out[i] = log_pos(x[i]);
+}
+#endif
 
 #define SEP_DISPATCH(FN, ...)                                                                  \
     switch (pb.lpc) {                                                                          \
@@ -1379,5 +1403,12 @@ int SEP_INFO(const DevProblem& pb, int solver, int batch, LaunchInfo* info) {
 #define SEPAIHRD_PHASE_PASS_APPLIED 0
 #endif
 int SEP_PHASED() { return SEPAIHRD_PHASE_PASS_APPLIED; }
+#if SEPAIHRD_ARITH_FMA
+int poisson_log_values(const double* d_x, int n, double* d_out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(log_values_kernel, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, (hipStream_t)stream, d_x, n, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace sepaihrd

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_f32_kernel(const DevP
         }
     }
     for (int k = lane; k < pb.nm_pad; k += WAVE) lds_mends[k] = pb.mends[k];
+    stage_log_table(lane, WAVE);  // the (fp64) Poisson term's log reads its table from LDS
     __syncthreads();
     const double* th = lds_theta + g * P;
     auto scalar_slot = [&](int slot) -> double {
@@ -547,6 +548,7 @@ int info_f32_one(const DevProblem& pb, LaunchInfo* info) {
     info->vgprs = attr.numRegs;
     info->sgprs = 0;
     info->lds_static = (int)attr.sharedSizeBytes;
+    info->lds_dynamic = (int)f32_lds_bytes(pb);
     info->scratch = (int)attr.localSizeBytes;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, WAVE, f32_lds_bytes(pb)) != hipSuccess) nb = -1;

@@ -94,6 +94,7 @@ EXPORTED_SYMBOLS = (
     "sepaihrd_mh_seed_streams", "sepaihrd_mh_draw_first", "sepaihrd_mh_keep_scale_on_device", "sepaihrd_mh_read_run_state",
     "sepaihrd_mh_read_sample_values", "sepaihrd_mh_read_accept_trace",
     "sepaihrd_device_libm_check", "sepaihrd_mh_read_failure_counts", "sepaihrd_mh_snapshot_begin", "sepaihrd_mh_snapshot_end",
+    "sepaihrd_device_log_values",
 )
 
 _lib = None
@@ -173,6 +174,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.sepaihrd_mh_read_sample_values.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.sepaihrd_mh_read_accept_trace.argtypes = [vp, vp]
     lib.sepaihrd_device_libm_check.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.sepaihrd_device_log_values.argtypes = [vp, vp, C.c_int32, vp]
     lib.sepaihrd_mh_read_failure_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.sepaihrd_mh_snapshot_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     lib.sepaihrd_mh_snapshot_end.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -375,6 +377,13 @@ class HipObjective:
         a, b = C.c_int32(-1), C.c_int32(-1)
         self._check(self.lib.sepaihrd_device_libm_check(self.ctx, C.byref(a), C.byref(b)), "device_libm_check")
         return a.value, b.value
+
+    def device_log_values(self, x) -> np.ndarray:
+        """The Poisson term's log as the device evaluates it (csrc/sepaihrd_dev_common.inc log_pos), on positive normal x."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        out = np.empty_like(x)
+        self._check(self.lib.sepaihrd_device_log_values(self.ctx, x.ctypes.data, x.size, out.ctypes.data), "device_log_values")
+        return out
 
     def kernel_info(self, batch: int = 0) -> dict:
         """Resource report of the integrator kernel a launch of `batch` chains uses (0: the large-batch kernel)."""

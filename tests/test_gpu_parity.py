@@ -602,3 +602,27 @@ def test_reference_suite_streams_enter_separately(mm, oracle_py, ref_fixture):
         np.testing.assert_allclose(parts, ref, rtol=1e-10)
         for j in range(3):
             assert (parts[j] != base[j]) == (j == k)
+
+
+def test_poisson_term_log_is_the_hosts_log(mm, shipped):
+    """The log of the Poisson term (the reference calls std::log, SEPAIHRDObjectiveFunction.cpp:264-276) is the table path of
+    glibc's log on the constants extracted from this image's libm (csrc/sepaihrd_dev_common.inc log_pos): outside glibc's
+    near-one window it has std::log's bits, inside it stays within 1e-17 absolute of the true log (2e-17 of the host's
+    rounded one) -- a term obs log(sim) of a sum near 1e5
+    needs no relative accuracy of a result near zero."""
+    import math
+    rng = np.random.default_rng(5)
+    lo_edge, hi_edge = 1.0 - 2.0 ** -4, 1.0 + float.fromhex("0x1.09p-4")
+    x = np.concatenate([
+        10.0 ** rng.uniform(-10.0, 7.0, 60000),                 # sim + 1e-10 of every size the likelihood sees
+        rng.uniform(lo_edge, hi_edge, 20000),                   # the window glibc treats with its log1p polynomial
+        np.nextafter(lo_edge, 0.0) * np.ones(1), np.array([lo_edge, hi_edge, np.nextafter(hi_edge, 0.0)]),
+        np.array([1e-10, 1.0 + 1e-10, 1.0, 0.5, 2.0, 1.5, np.nextafter(1.0, 0.0), np.nextafter(1.0, 2.0), 1e300, 2.3e-308]),
+        2.0 ** rng.integers(-30, 30, 200).astype(float),        # exact powers of two: z = 1, r at a table boundary
+    ])
+    got = mm.HipObjective(shipped).device_log_values(x)
+    ref = np.array([math.log(v) for v in x])
+    inside = (x >= lo_edge) & (x < hi_edge)
+    assert inside.sum() > 20000 and (~inside).sum() > 60000
+    assert np.array_equal(got[~inside].view(np.uint64), ref[~inside].view(np.uint64))
+    assert np.abs(got[inside] - ref[inside]).max() < 2e-17
