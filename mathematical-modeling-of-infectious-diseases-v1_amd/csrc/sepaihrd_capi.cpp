@@ -477,7 +477,7 @@ sepaihrd_ctx* sepaihrd_create(const sepaihrd_problem* pb, int device, char* err,
         sepaihrd_destroy(ctx);
         return nullptr;
     }
-    if (eval_lds_bytes(d) > 64 * 1024) {
+    if (eval_lds_bytes(d) + LOG_TABLE_LDS_BYTES > 64 * 1024) {  // dynamic + the static 2 KB of the Poisson term's log table
         set_err(err, errlen, "n_params too large for the LDS staging buffer");
         sepaihrd_destroy(ctx);
         return nullptr;

@@ -146,6 +146,7 @@ inline int lanes_per_chain(int n) {
 //   [.., + cpw*(nm+1))            per-chain beta*kappa of every merged segment
 //   [.., + cpw*P)                 constrained theta of the wave's chains (prologue only)
 constexpr int MAX_TIMES = 12288;  // output grid staged in LDS (96 KiB at the cap)
+constexpr int LOG_TABLE_LDS_BYTES = 128 * 2 * 8;  // lds_log_table (csrc/sepaihrd_dev_common.inc): static LDS of every kernel that takes logs
 constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;  // LDS-DMA landing zone of the inline-likelihood build
 constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is always used
 // Which form of the likelihood a launch uses is decided in the kernel translation unit (split_pays in
