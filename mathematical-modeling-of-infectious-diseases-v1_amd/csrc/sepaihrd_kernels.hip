@@ -598,16 +598,12 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
             return (do_it && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
         };
         const double tH = term(oH, 0), tI = term(oI, 1), tD = term(oD, 2);
-        auto row_sum = [&](double tv) -> double {  // ages ascending: calculateSingleLogLikelihood's inner loop
-            double rs = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
-            [&]<int... J>(std::integer_sequence<int, J...>) {
-                ((rs += group_bcast<LPC, J + 1>(tv)), ...);
-            }(std::make_integer_sequence<int, LPC - 1>{});
-            return rs;
-        };
-        llH += row_sum(tH);
-        llICU += row_sum(tI);
-        llD += row_sum(tD);
+        const double tv3[3] = {tH, tI, tD};
+        double rs3[3];
+        row_sums3<LPC>(tv3, rs3);  // ages ascending: calculateSingleLogLikelihood's inner loop
+        llH += rs3[0];
+        llICU += rs3[1];
+        llD += rs3[2];
         if constexpr (LL_IN_LDS) {
             lds_ll[lane] = prevH; lds_ll[WAVE + lane] = prevICU; lds_ll[2 * WAVE + lane] = prevD;
             lds_ll[3 * WAVE + lane] = llH; lds_ll[4 * WAVE + lane] = llICU; lds_ll[5 * WAVE + lane] = llD;
@@ -983,7 +979,7 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     }
     const double* cur = out.cum + (size_t)k * 3 * stride + c;
     const double* rec = pb.grid + ((size_t)k * LPC + age) * 4;  // {obs_H, obs_ICU, obs_D, t_{k+1}}
-    double rs[3];
+    double rs[3], tv3[3];
     SEP_UNROLL
     for (int s = 0; s < 3; ++s) {
         const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU; streams are H, ICU, D
@@ -992,13 +988,9 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
         const double obs = rec[s];
         const double sim = inc + 1e-10;
         const double v = obs * log_pos(sim) - sim;
-        const double tv = (valid && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
-        double r = group_bcast<LPC, 0>(tv);  // "0.0 +" dropped: value-identical
-        [&]<int... J>(std::integer_sequence<int, J...>) {
-            ((r += group_bcast<LPC, J + 1>(tv)), ...);
-        }(std::make_integer_sequence<int, LPC - 1>{});
-        rs[s] = r;
+        tv3[s] = (valid && obs >= 0.0 && isfinite(obs)) ? v : 0.0;
     }
+    row_sums3<LPC>(tv3, rs);
     if (valid && age == 0) {
         double* dst = out.rows + (size_t)k * 3 * cum_chains + chain;
         dst[0] = rs[0];
