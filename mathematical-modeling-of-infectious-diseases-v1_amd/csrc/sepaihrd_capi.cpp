@@ -1363,6 +1363,18 @@ int sepaihrd_device_libm_check(sepaihrd_ctx* ctx, int32_t* n_log_diff, int32_t* 
     return SEPAIHRD_OK;
 }
 
+namespace {
+// does a batch of C chains fill the chip with two integrator waves per SIMD (the same threshold as launch_one's)?
+bool mh_draws_behind_the_evaluation(const sepaihrd_ctx* ctx, int C) {
+    if (const char* e = std::getenv("SEPAIHRD_MH_DRAW")) {
+        if (std::string(e) == "overlap") return false;
+        if (std::string(e) == "serial") return true;
+    }
+    const long long chains_per_wave = WAVE / (ctx->dp.lpc > 0 ? ctx->dp.lpc : 1);
+    return (C + chains_per_wave - 1) / chains_per_wave > 2 * 1024;  // more than one round of two waves per SIMD
+}
+}  // namespace
+
 int sepaihrd_device_log_values(sepaihrd_ctx* ctx, const double* x, int32_t n, double* out) {
     if (!ctx || n < 0 || (n > 0 && (!x || !out))) return SEPAIHRD_E_INVALID_ARG;
     if (n == 0) return SEPAIHRD_OK;
@@ -1633,7 +1645,15 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
             HIP_TRY(hipMemcpyAsync(mh->d_test + C, mh->h_test + C, 2 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
                     return SEPAIHRD_E_HIP);
         uint8_t* const prev_flags = reinterpret_cast<uint8_t*>(static_cast<double*>(mh->d_test_out) + C);
-        if (sampler_draw(mh->st, prev_flags, 0, mh->d_test, mh->d_z_stage, mh->d_test + 3 * (size_t)C, last ? 0 : 1, cs) != 0) {
+        // The draws of test i + 1 need nothing of evaluation i, so they run beside it on the copy stream -- as long as the
+        // evaluation leaves room.  A saturating batch (two 256-register waves on every SIMD) leaves none: the draw kernel's
+        // 65 536 small waves then take the slots of retiring integrator waves and hold up the next ones (round 4, 65 536
+        // chains: the evaluation stretched from 2.9 to 3.6 ms around 0.1 ms of draws).  From that size on the draws queue
+        // behind the evaluation on the main stream instead (65 536 chains: 4.01 -> 3.43 ms per iteration; a batch of exactly
+        // one round, 32 768 chains, still gains from the overlap -- 1.95 against 2.00 -- as the draws fill the round's tail;
+        // a low-priority copy stream changed nothing).  SEPAIHRD_MH_DRAW=overlap|serial overrides (A/B runs).
+        const bool serial_draw = mh_draws_behind_the_evaluation(ctx, C);
+        if (sampler_draw(mh->st, prev_flags, 0, mh->d_test, mh->d_z_stage, mh->d_test + 3 * (size_t)C, last ? 0 : 1, serial_draw ? st : cs) != 0) {
             ctx->last_error = "mh_step_tested: draw launch failed";
             return SEPAIHRD_E_HIP;
         }

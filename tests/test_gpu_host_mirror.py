@@ -968,3 +968,22 @@ def test_checkpoints_and_progress_lines_while_the_device_resident_sampler_runs(m
     for name in ("posterior_trace_checkpoint.csv", "posterior_trace_final.csv", "posterior_trace.csv", "posterior_trace_checkpoint_chain1.csv"):
         assert (out2 / name).read_bytes() == (out3 / name).read_bytes(), name
     assert (tmp_path / "host.log").read_text().replace(str(out2), "<dir>") == (tmp_path / "dev3.log").read_text().replace(str(out3), "<dir>")
+
+
+def test_draws_queued_behind_the_evaluation_give_the_overlapped_result(mm, shipped, monkeypatch):
+    """The draws of the next accept test run beside the evaluation on the copy stream, except for batches that fill the chip
+    with two integrator waves per SIMD, where they queue behind it on the main stream (csrc/sepaihrd_capi.cpp
+    mh_draws_behind_the_evaluation).  Where the draw kernel is launched changes nothing it computes: the same run with
+    either placement forced gives the same accept traces, samples and final state, including over a covariance refresh."""
+    pb = shipped.with_(arith=mm.ARITH_FMA, constraint_mode=1)
+    from mmid_amd import draws
+    x0 = draws.jitter_draws(pb, 4, 21)
+    kw = dict(seed=5, iterations=260, burn_in=60, adaptation_period=100, thinning=10, device_state=True, device_streams=True)
+    out = {}
+    for mode in ("overlap", "serial"):
+        monkeypatch.setenv("SEPAIHRD_MH_DRAW", mode)
+        out[mode] = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
+    monkeypatch.delenv("SEPAIHRD_MH_DRAW")
+    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+        assert np.array_equal(out["overlap"][k], out["serial"][k]), k
+    assert 0 < out["serial"]["accept_trace"].mean() < 1
