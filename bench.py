@@ -333,8 +333,24 @@ def measure_other_workload(mm, torch, key, precision, steps, arith, dev, local_r
         "status_counts": np.bincount(status, minlength=5).tolist(),
     }
     hip.close()
+    theta_host = theta.cpu().numpy() if name == "c2" and precision == "f64" else None
     del theta, d_ll, d_status, d_acc, d_rej
     torch.cuda.empty_cache()
+    if theta_host is not None:
+        # configs[2] is the reference's largest single-process run: the whole Adaptive-Metropolis iteration at its size (streams,
+        # accept test, scale and covariance adaptation on the device; one short run, one chain group)
+        try:
+            iters = 200
+            host = mm.HostObjective(pb)
+            host.metropolis_hastings(theta_host[:16], 1, 4, 1, device_state=True)
+            r = host.metropolis_hastings(theta_host, 1, iters, iters // 3, adaptation_period=50, thinning=iters, device_state=True)
+            ms = r["loop_seconds"] / (iters - 1) * 1e3
+            out["sampler_iteration"] = {"iterations": iters, "ms_per_iteration": ms, "proposals_per_s": B / (ms * 1e-3),
+                                        "vs_ms_per_step": ms / wall_ms, "acceptance": float(r["accepted"].mean() / (iters - 1)),
+                                        "note": "draws of the next test queue behind the evaluation at this size (DESIGN.md 6)"}
+            del host
+        except Exception as e:  # the host library is optional
+            out["sampler_iteration"] = {"error": repr(e)}
     return out
 
 

@@ -23,6 +23,8 @@ for k, v in (d.get("other_workloads") or {}).items():
     if "error" in v:
         print(k, "ERROR", v["error"]); continue
     print("%-7s %.4g evals/s  ms/step %.3f  kernel %.3f + ll %.3f  frac %.3f  of step %.3f  vgprs %d  %s" % (k, v["evals_per_s"], v["ms_per_step"], v["kernel_ms"], v["likelihood_pass_ms"], v["roofline"]["frac"], v["roofline"]["frac_of_step"], v["kernel_info"]["vgprs"], v["likelihood_form"]))
+    if v.get("sampler_iteration"):
+        print("        sampler at this size:", v["sampler_iteration"])
 sp = d.get("sampler_pipeline") or {}
 print("sampler", {k: sp.get(k) for k in ("ms_per_iteration", "proposals_per_s", "accept_trace_mismatches_vs_strict", "error")}, (sp.get("long_run") or {}).get("ms_per_iteration"))
 print("cpu", (d.get("cpu_baseline") or {}).get("value"), (d.get("cpu_baseline") or {}).get("cores"))
