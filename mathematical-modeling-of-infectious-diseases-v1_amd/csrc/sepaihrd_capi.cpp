@@ -911,6 +911,8 @@ struct sepaihrd_mh {
     // sepaihrd_mh_stage_normals / sepaihrd_mh_step: a second normals buffer filled by a copy stream while the
     // evaluation runs, and ONE packed upload per iteration (accept flags, scales, re-drawn rows) from pinned memory
     double* d_z_stage = nullptr;
+    double* d_lz = nullptr;          // [2][C][P] L z of both continuations, formed beside the evaluation (sampler_lz)
+    bool lz_ready = false;           // d_lz holds the products of the normals staged for the coming test
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_staged = nullptr;
     bool staged = false;
@@ -1131,6 +1133,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     mh->d_status = mh->d_loglik ? reinterpret_cast<int32_t*>(mh->d_loglik + C) : nullptr;
     dalloc((void**)&mh->d_accept, (size_t)C);
     dalloc((void**)&mh->d_z_stage, CP * sizeof(double));
+    dalloc((void**)&mh->d_lz, 2 * CP * sizeof(double));
     dalloc((void**)&mh->d_lp, (size_t)C * sizeof(double));
     dalloc((void**)&mh->d_best_lp, (size_t)C * sizeof(double));
     dalloc((void**)&mh->d_test, (3 * (size_t)C + CP) * sizeof(double));
@@ -1365,6 +1368,10 @@ int sepaihrd_device_libm_check(sepaihrd_ctx* ctx, int32_t* n_log_diff, int32_t* 
 
 namespace {
 // does a batch of C chains fill the chip with two integrator waves per SIMD (the same threshold as launch_one's)?
+bool mh_lz_ahead_wanted() {
+    const char* e = std::getenv("SEPAIHRD_MH_LZ");
+    return !(e && std::string(e) == "fused");
+}
 bool mh_draws_behind_the_evaluation(const sepaihrd_ctx* ctx, int C) {
     if (const char* e = std::getenv("SEPAIHRD_MH_DRAW")) {
         if (std::string(e) == "overlap") return false;
@@ -1634,6 +1641,7 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
     HIP_TRY(hipSetDevice(ctx->device), ctx, return SEPAIHRD_E_HIP);
     hipStream_t st = mh->stream, cs = mh->copy_stream;
     const size_t CP = (size_t)C * P;
+    mh->lz_ready = false;
     // the test's inputs travel on the copy stream while the evaluation still runs; they may not overwrite what the
     // previous proposal is reading
     if (mh->proposed_once) HIP_TRY(hipStreamWaitEvent(cs, mh->ev_last_proposed, 0), ctx, return SEPAIHRD_E_HIP);
@@ -1658,6 +1666,15 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
             return SEPAIHRD_E_HIP;
         }
         mh->staged = true;
+        // ... and, when the draws run beside the evaluation and no covariance refresh separates this test from its proposal,
+        // L z of both continuations too: the launch between two evaluations then reads no factor (SEPAIHRD_MH_LZ=fused: A/B)
+        if (!serial_draw && !last && adapt <= 1 && mh->st.P <= 200 && mh_lz_ahead_wanted()) {
+            if (sampler_lz(mh->st, mh->d_z_stage, mh->d_test + 3 * (size_t)C, mh->d_lz, mh->d_lz + CP, cs) != 0) {
+                ctx->last_error = "mh_step_tested: L z launch failed";
+                return SEPAIHRD_E_HIP;
+            }
+            mh->lz_ready = true;
+        }
     } else
     HIP_TRY(hipMemcpyAsync(mh->d_test, mh->h_test, (3 * (size_t)C + (last ? 0 : CP)) * sizeof(double), hipMemcpyHostToDevice, cs), ctx,
             return SEPAIHRD_E_HIP);
@@ -1671,7 +1688,8 @@ int sepaihrd_mh_step_tested(sepaihrd_mh* mh, double gamma, int adapt, int last) 
         // (the staged normals landed before the test's inputs: same copy stream, staged first -- ev_test_up covers them)
         if (sampler_test_commit_propose(mh->st, ctx->dp, mh->d_loglik, mh->d_status, mh->d_test, mh->d_test + C, mh->d_test + 2 * (size_t)C,
                                         mh->d_lp, mh->d_best_lp, mh->d_scale_sel, d_flags, d_values, mh->d_z_stage,
-                                        mh->d_test + 3 * (size_t)C, mh->rows, st) != 0) {
+                                        mh->d_test + 3 * (size_t)C, mh->rows, st, mh->lz_ready ? mh->d_lz : nullptr,
+                                        mh->lz_ready ? mh->d_lz + CP : nullptr) != 0) {
             ctx->last_error = "mh_step_tested: launch failed";
             return SEPAIHRD_E_HIP;
         }

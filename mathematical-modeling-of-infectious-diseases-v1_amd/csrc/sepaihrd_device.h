@@ -72,6 +72,18 @@ struct EvalOutputs {
     int32_t force_split;        // always park the increments in `cum` (ensemble summaries read them)
 };
 inline size_t workspace_cum_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains * pb.lpc; }
+// Layout of the parked daily increments (D, CumH, CumICU of every (chain, age) column and output day): WAVE-major,
+// cum[column / 64][T][3][64].  A wave of the integrator writes its own contiguous T x 1.5 KB, day after day -- one or two
+// pages for the whole run.  (Through round 4's first builds it was cum[T][3][columns]: successive days of a wave lay
+// 24 B x columns apart, every output touched three new pages, and the kernel ran 1.6 x slower behind any other kernel
+// that had pushed the page-table lines out of the cache: 16 384 chains, 0.91 -> 1.46 ms, tools/probe_dispatch_placement.py.)
+constexpr size_t CUM_ROW_DOUBLES = 3 * WAVE;  // one day of one wave
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t cum_index(int T, size_t column, int day, int comp) {
+    return ((column / WAVE) * (size_t)T + (size_t)day) * CUM_ROW_DOUBLES + (size_t)comp * WAVE + (column % WAVE);
+}
 inline size_t workspace_rows_doubles(const DevProblem& pb, size_t chains) { return (size_t)pb.T * 3 * chains; }
 
 // sepaihrd_kernel_info::likelihood_form (include/sepaihrd_hip.h: SEPAIHRD_LL_*)
@@ -113,7 +125,7 @@ struct EnsembleArgs {
     int runup_offset;         // index of the first output time >= 0
     int n_probs;
     size_t cum_stride;        // columns of the integrator workspace (launch chains * lpc)
-    const double* cum;        // [T][3][cum_stride] daily increments of D, CumH, CumICU
+    const double* cum;        // daily increments of D, CumH, CumICU: see cum_index()
     const int32_t* wstatus;   // [S] integrator status
     const double* traj;       // [S][T][11][n] or null (seroprevalence needs S(t))
     double total_pop;
@@ -148,7 +160,10 @@ inline int lanes_per_chain(int n) {
 constexpr int MAX_TIMES = 12288;  // output grid staged in LDS (96 KiB at the cap)
 constexpr int LOG_TABLE_LDS_BYTES = 128 * 2 * 8;  // lds_log_table (csrc/sepaihrd_dev_common.inc): static LDS of every kernel that takes logs
 constexpr int LDS_REC_DOUBLES = 2 * WAVE * 2;  // LDS-DMA landing zone of the inline-likelihood build
-constexpr int SPLIT_LL_MAX_BLOCKS = 1024;      // waves up to which the separate likelihood pass is always used
+#ifndef SEPAIHRD_SPLIT_LL_MAX_BLOCKS
+#define SEPAIHRD_SPLIT_LL_MAX_BLOCKS 1024
+#endif
+constexpr int SPLIT_LL_MAX_BLOCKS = SEPAIHRD_SPLIT_LL_MAX_BLOCKS;  // waves up to which the separate likelihood pass is always used
 // Which form of the likelihood a launch uses is decided in the kernel translation unit (split_pays in
 // csrc/sepaihrd_kernels.hip): up to one wave per SIMD the chip is not full and the separate pass always wins; beyond that it
 // wins only where the integrator WITHOUT the inline logs fits two waves per SIMD (Dopri5 in fma arithmetic up to 4 age
@@ -231,7 +246,11 @@ int sampler_accept_test(const SamplerState& s, const int row, const double* d_lo
 int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, const double* d_loglik, const int32_t* d_status,
                                 const double* d_log_u, const double* d_scale_reject, const double* d_scale_accept, double* d_lp,
                                 double* d_best_lp, double* d_scale_sel, uint8_t* d_flags, double* d_values, const double* d_z_uniform,
-                                const double* d_z_plain, int row, void* stream);
+                                const double* d_z_plain, int row, void* stream, const double* d_lz_uniform = nullptr,
+                                const double* d_lz_plain = nullptr);
+// L z of both continuations' normals ahead of the test (d_lz_*: [C][P]); the fused launch above then takes them instead of
+// reading the factor itself
+int sampler_lz(const SamplerState& s, const double* d_z_uniform, const double* d_z_plain, double* d_lz_uniform, double* d_lz_plain, void* stream);
 int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const double* d_z_uniform, const double* d_z_plain,
                            const uint8_t* d_flags, const double* d_scale, void* stream);
 int sampler_patch_normals(double* d_z, const int32_t* d_chain, const double* d_rows, int n_patch, int P, void* stream);

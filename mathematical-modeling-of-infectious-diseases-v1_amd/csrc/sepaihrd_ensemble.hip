@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVE) void ensemble_series_kernel(const EnsembleArg
         for (int d = 0; d < DAYS; ++d) {
             const size_t k = (size_t)(a.runup_offset + (t0 + d < a.Tp ? t0 + d : a.Tp - 1));
 #pragma unroll
-            for (int ser = 0; ser < 3; ++ser) inc[d][ser] = ok ? a.cum[(k * 3 + comp_of[ser]) * a.cum_stride + col] : 0.0;
+            for (int ser = 0; ser < 3; ++ser) inc[d][ser] = ok ? a.cum[cum_index(a.T, col, k, comp_of[ser])] : 0.0;
         }
 #pragma unroll
         for (int d = 0; d < DAYS; ++d) {

@@ -533,8 +533,7 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
 
     // Observer at output index k for the chains with do_it set.  The likelihood only needs the daily
     // increments of D, CumH, CumICU and never feeds back into the dynamics.
-    const size_t cum_stride = (size_t)cum_chains * LPC;
-    double* const cum_lane = out.cum + (size_t)(chain0 + grp) * LPC + age;  // own column, shadow groups too
+    double* const cum_lane = out.cum + cum_index(T, (size_t)(chain0 + grp) * LPC + age, 0, 0);  // own column, shadow groups too
     double prevD = x[8], prevH = x[9], prevICU = x[10];  // row 0: X(0) - init_state = 0
     double llH = 0.0, llICU = 0.0, llD = 0.0;             // INLINE_LL accumulators
     // Two-waves-per-SIMD builds of the tolerance arithmetic keep that state in LDS (LL_IN_LDS, round 4): with it the 4-age
@@ -566,10 +565,10 @@ __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProbl
     // split form: park the raw increments (one coalesced 512-B store per wave and compartment)
     auto observe_store = [&](bool do_it, int k) {
         if (do_it) {
-            double* dst = cum_lane + (size_t)k * 3 * cum_stride;
+            double* dst = cum_lane + (size_t)k * CUM_ROW_DOUBLES;
             dst[0] = x[8] - prevD;
-            dst[cum_stride] = x[9] - prevH;
-            dst[2 * cum_stride] = x[10] - prevICU;
+            dst[WAVE] = x[9] - prevH;
+            dst[2 * WAVE] = x[10] - prevICU;
             prevD = x[8]; prevH = x[9]; prevICU = x[10];
             store_traj(k);
         }
@@ -963,7 +962,6 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
     stage_log_table(threadIdx.x, WAVE * LL_DAYS_PER_BLOCK);
     __syncthreads();
     if (k >= pb.T) return;
-    const size_t stride = (size_t)cum_chains * LPC;
     const size_t chain = col / LPC;
     const int age = (int)(col % LPC);
     const bool valid = chain < (size_t)B;
@@ -977,13 +975,13 @@ __global__ __launch_bounds__(WAVE * LL_DAYS_PER_BLOCK) void sepaihrd_ll_terms_ke
         }
         return;
     }
-    const double* cur = out.cum + (size_t)k * 3 * stride + c;
+    const double* cur = out.cum + cum_index(pb.T, c, k, 0);
     const double* rec = pb.grid + ((size_t)k * LPC + age) * 4;  // {obs_H, obs_ICU, obs_D, t_{k+1}}
     double rs[3], tv3[3];
     SEP_UNROLL
     for (int s = 0; s < 3; ++s) {
         const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU; streams are H, ICU, D
-        double inc = cur[(size_t)comp * stride];  // X(k) - X(k-1), written by the integrator
+        double inc = cur[(size_t)comp * WAVE];  // X(k) - X(k-1), written by the integrator
         inc = (inc < 0.0) ? 0.0 : inc;            // cwiseMax(0.0)
         const double obs = rec[s];
         const double sim = inc + 1e-10;
@@ -1022,8 +1020,7 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_serial_kernel(const DevProbl
     const bool valid = chain < B;
     const size_t c = valid ? (size_t)chain : 0;
     const int comp = (s == 0) ? 1 : (s == 1) ? 2 : 0;  // cum rows are D, CumH, CumICU
-    const size_t stride = (size_t)cum_chains * LPC;
-    const double* cur = out.cum + (size_t)comp * stride + c * LPC + part * AGES;
+    const double* cur = out.cum + cum_index(pb.T, c * LPC + part * AGES, 0, comp);
     double acc = 0.0;
     // the sums are a dependent chain, the loads are not: DAYS days of increments are requested at a time
     constexpr int DAYS = (AGES <= 4) ? 8 : (AGES == 8 ? 4 : 2);
@@ -1032,7 +1029,7 @@ __global__ __launch_bounds__(WAVE) void sepaihrd_ll_serial_kernel(const DevProbl
         SEP_UNROLL
         for (int d = 0; d < DAYS; ++d) {
             const int k = (k0 + d < pb.T) ? k0 + d : pb.T - 1;
-            const double* row = cur + (size_t)k * 3 * stride;
+            const double* row = cur + (size_t)k * CUM_ROW_DOUBLES;
             if constexpr (AGES % 4 == 0) {
                 SEP_UNROLL
                 for (int a = 0; a < AGES; a += 4) {
@@ -1211,7 +1208,16 @@ inline bool split_pays(size_t blocks) {
     }();
     if (forced >= 0 && blocks > (size_t)SPLIT_LL_MAX_BLOCKS) return forced != 0;
 #endif
+    // Between half a wave and one wave per SIMD the tolerance build's Dopri5 integrator keeps its likelihood inline since
+    // round 4.  The separate-pass kernel fits two of its 255-register waves on a SIMD, and behind any other kernel that has
+    // touched tens of MB the dispatcher does pair them up while other SIMDs stay empty (16 384 chains: 0.95 ms in a loop of
+    // evaluations, 1.46 ms behind a 64-MB elementwise kernel or inside the sampler; tools/probe_dispatch_placement.py); the
+    // inline kernel needs 273 registers, cannot be paired, and with the table log costs 1.10 ms against 0.95 + 0.21.
+    if (SEPAIHRD_ARITH_FMA != 0 && SOLVER == 0 && LPC >= 2 && blocks > (size_t)SPLIT_LL_MAX_BLOCKS / 2 && blocks <= (size_t)SPLIT_LL_MAX_BLOCKS) return false;
     if (blocks <= (size_t)SPLIT_LL_MAX_BLOCKS) return true;
+#ifdef SEPAIHRD_SPLIT_ONLY_BELOW_MAX  // A/B builds: the inline forms everywhere above SEPAIHRD_SPLIT_LL_MAX_BLOCKS
+    return false;
+#endif
     if (!(SEPAIHRD_ARITH_FMA != 0 && SOLVER == 0)) return false;
     // from two waves per SIMD on the tolerance build's 4-age Dopri5 integrator keeps its logs inline at 256 registers (LL_IN_LDS)
     if (dopri5_two_waves<LPC>() && blocks >= (size_t)2 * 1024) return false;

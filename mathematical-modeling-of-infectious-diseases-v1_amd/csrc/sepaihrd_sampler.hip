@@ -234,7 +234,8 @@ constexpr int FUSED_ROWS_PER_LANE = (200 + WAVE - 1) / WAVE;  // P <= 200 (sepai
 __global__ __launch_bounds__(2 * WAVE) void mh_test_commit_propose_kernel(const SamplerState s, const DevProblem pb,
         const double* __restrict__ loglik, const int32_t* __restrict__ status, const double* __restrict__ log_u,
         const double* __restrict__ scale_reject, const double* __restrict__ scale_accept, double* lp, double* best_lp, double* scale_sel,
-        uint8_t* flags, double* values, const double* z_uniform, const double* z_plain, const int row) {
+        uint8_t* flags, double* values, const double* z_uniform, const double* z_plain, const int row,
+        const double* __restrict__ lz_uniform, const double* __restrict__ lz_plain) {
     __shared__ double xs[200];
     __shared__ double zu[200], zp[200];
     __shared__ double sc_sh;
@@ -245,7 +246,15 @@ __global__ __launch_bounds__(2 * WAVE) void mh_test_commit_propose_kernel(const 
     const bool dot_wave = threadIdx.x < WAVE;
     double su[FUSED_ROWS_PER_LANE], sp[FUSED_ROWS_PER_LANE];       // wave 0: L z of both continuations, rows lane + 64 q
     double x_cur[FUSED_ROWS_PER_LANE], x_prop[FUSED_ROWS_PER_LANE];  // wave 1: the chain's state and its proposal
-    if (dot_wave) {
+    if (dot_wave && lz_uniform != nullptr) {
+        // L z of both continuations was formed while the evaluation ran (mh_lz_kernel, same chol_row_dot2): two loads
+#pragma unroll
+        for (int q = 0; q < FUSED_ROWS_PER_LANE; ++q) {
+            const int i = lane + q * WAVE;
+            su[q] = i < P ? lz_uniform[(size_t)c * P + i] : 0.0;
+            sp[q] = i < P ? lz_plain[(size_t)c * P + i] : 0.0;
+        }
+    } else if (dot_wave) {
         for (int i = lane; i < P; i += WAVE) {
             zu[i] = z_uniform[(size_t)c * P + i];
             zp[i] = z_plain[(size_t)c * P + i];
@@ -319,6 +328,30 @@ __global__ __launch_bounds__(2 * WAVE) void mh_test_commit_propose_kernel(const 
                 s.prop[(size_t)c * P + i] = constrain(raw, pb.lower[i], pb.upper[i], pb.has_bounds[i], pb.constraint_mode);
             }
         }
+    }
+}
+
+// L z for the normals of BOTH continuations of the next test, ahead of it: the product needs the factor and the normals, not
+// the running evaluation, and reading the factor (15.6 KB per chain at P = 62: 64 MB per 4096 chains) is what the fused
+// test + commit + proposal launch spent its 18 us on.  Queued behind the draws on the copy stream it runs beside the
+// evaluation; the launch between two evaluations is then the test and two loads per row.  One wave per chain, the same
+// chol_row_dot2 on the same operands as the fused kernel's first wave: the same bits.
+__global__ __launch_bounds__(WAVE) void mh_lz_kernel(const SamplerState s, const double* __restrict__ z_uniform, const double* __restrict__ z_plain,
+                                                     double* __restrict__ lz_uniform, double* __restrict__ lz_plain) {
+    __shared__ double zu[200], zp[200];
+    const int c = blockIdx.x, P = s.P, lane = threadIdx.x;
+    for (int i = lane; i < P; i += WAVE) {
+        zu[i] = z_uniform[(size_t)c * P + i];
+        zp[i] = z_plain[(size_t)c * P + i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double* Lc = s.chol + (size_t)c * P * P;
+    for (int i = lane; i < P; i += WAVE) {
+        double a, b;
+        chol_row_dot2(Lc, zu, zp, i, P, a, b);
+        lz_uniform[(size_t)c * P + i] = a;
+        lz_plain[(size_t)c * P + i] = b;
     }
 }
 
@@ -833,10 +866,16 @@ int sampler_propose_select(const SamplerState& s, const DevProblem& pb, const do
 int sampler_test_commit_propose(const SamplerState& s, const DevProblem& pb, const double* d_loglik, const int32_t* d_status,
                                 const double* d_log_u, const double* d_scale_reject, const double* d_scale_accept, double* d_lp,
                                 double* d_best_lp, double* d_scale_sel, uint8_t* d_flags, double* d_values, const double* d_z_uniform,
-                                const double* d_z_plain, int row, void* stream) {
+                                const double* d_z_plain, int row, void* stream, const double* d_lz_uniform, const double* d_lz_plain) {
     if (s.P > 200) return -3;
     hipLaunchKernelGGL(mh_test_commit_propose_kernel, dim3(s.C), dim3(2 * WAVE), 0, static_cast<hipStream_t>(stream), s, pb, d_loglik, d_status,
-                       d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values, d_z_uniform, d_z_plain, row);
+                       d_log_u, d_scale_reject, d_scale_accept, d_lp, d_best_lp, d_scale_sel, d_flags, d_values, d_z_uniform, d_z_plain, row,
+                       d_lz_uniform, d_lz_plain);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int sampler_lz(const SamplerState& s, const double* d_z_uniform, const double* d_z_plain, double* d_lz_uniform, double* d_lz_plain, void* stream) {
+    if (s.P > 200) return -3;
+    hipLaunchKernelGGL(mh_lz_kernel, dim3(s.C), dim3(WAVE), 0, static_cast<hipStream_t>(stream), s, d_z_uniform, d_z_plain, d_lz_uniform, d_lz_plain);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -973,17 +973,23 @@ def test_checkpoints_and_progress_lines_while_the_device_resident_sampler_runs(m
 def test_draws_queued_behind_the_evaluation_give_the_overlapped_result(mm, shipped, monkeypatch):
     """The draws of the next accept test run beside the evaluation on the copy stream, except for batches that fill the chip
     with two integrator waves per SIMD, where they queue behind it on the main stream (csrc/sepaihrd_capi.cpp
-    mh_draws_behind_the_evaluation).  Where the draw kernel is launched changes nothing it computes: the same run with
-    either placement forced gives the same accept traces, samples and final state, including over a covariance refresh."""
+    mh_draws_behind_the_evaluation); beside the evaluation they are followed by L z of both continuations (mh_lz_kernel), which
+    the fused test + commit + proposal launch then takes instead of reading the factor itself.  Where the kernels are
+    launched changes nothing they compute: the same run with either placement forced, and with the look-ahead product on or
+    off, gives the same accept traces, samples and final state, including over covariance refreshes."""
     pb = shipped.with_(arith=mm.ARITH_FMA, constraint_mode=1)
     from mmid_amd import draws
     x0 = draws.jitter_draws(pb, 4, 21)
     kw = dict(seed=5, iterations=260, burn_in=60, adaptation_period=100, thinning=10, device_state=True, device_streams=True)
     out = {}
-    for mode in ("overlap", "serial"):
+    for mode, lz in (("overlap", "ahead"), ("overlap", "fused"), ("serial", "ahead")):
         monkeypatch.setenv("SEPAIHRD_MH_DRAW", mode)
-        out[mode] = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
+        monkeypatch.setenv("SEPAIHRD_MH_LZ", lz)
+        out[(mode, lz)] = mm.HostObjective(pb).metropolis_hastings(x0, **kw)
     monkeypatch.delenv("SEPAIHRD_MH_DRAW")
-    for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
-        assert np.array_equal(out["overlap"][k], out["serial"][k]), k
-    assert 0 < out["serial"]["accept_trace"].mean() < 1
+    monkeypatch.delenv("SEPAIHRD_MH_LZ")
+    ref = out[("overlap", "fused")]
+    for key, r in out.items():
+        for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
+            assert np.array_equal(r[k], ref[k]), (key, k)
+    assert 0 < ref["accept_trace"].mean() < 1

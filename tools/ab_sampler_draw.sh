@@ -1,4 +1,5 @@
 #!/bin/bash
+# SEPAIHRD_MH_LZ=fused|ahead in the environment selects where L z is formed (inside the fused launch / ahead, beside the evaluation).
 # Where the sampler's draw kernel runs (beside the evaluation on the copy stream / behind it on the main stream), per batch size:
 # ms per Adaptive-Metropolis iteration of a 300-iteration device-resident run.   tools/ab_sampler_draw.sh "c2 c3 c1"
 for W in ${1:-c2 c3}; do
