@@ -392,12 +392,22 @@ __device__ __forceinline__ void rk_stages_row_coef(const double cur, const doubl
 //          fill the chip (4096 chains: 1.24 -> 1.09 ms per step);
 //   true   three logs per output inside the wave, observation records prefetched by LDS-DMA -- best
 //          at saturation, where the separate pass would add HBM traffic to the same VALU work.
+// does the tolerance build's Dopri5 integrator of this lane count have a two-waves-per-SIMD form? (the comment at split_pays)
+template <int LPC>
+constexpr bool dopri5_two_waves() { return SEPAIHRD_ARITH_FMA != 0 && ((LPC == 4 && SEPAIHRD_LL_STATE_IN_LDS != 0) || LPC == 16); }
+// One-wave-per-SIMD forms that are launched for at most one wave per SIMD (<= 1024 workgroups; above that their two-wave
+// sibling takes over) declare a high accumulation register they never touch: the allocation passes 256 registers, two of
+// their waves no longer fit a SIMD, and the dispatcher cannot pair them up while other SIMDs stay empty (see split_pays).
+template <int LPC, int SOLVER, int WPS>
+constexpr bool one_wave_per_simd_only() { return WPS == 1 && (SOLVER == 1 || dopri5_two_waves<LPC>()); }
+
 template <int LPC, int SOLVER, int ARITH_FMA, int WPS, bool INLINE_LL>
 __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_kernel(const DevProblem pb,
                                                               const double* __restrict__ theta,
                                                               const int B, const EvalOutputs out,
                                                               const int cum_chains) {
     constexpr int CPW = WAVE / LPC;
+    if constexpr (one_wave_per_simd_only<LPC, SOLVER, WPS>()) asm volatile("" ::: "a31");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // the inline-likelihood builds take the next grid time from the observation record: no output grid in their LDS (it was
     // 8 KB per wave at 1001 days -- with 2 KB more for the log table a CU held 7 waves of the 16-age kernel instead of 8)
@@ -1196,8 +1206,7 @@ inline int ll_serial_min_waves() {
 // (tools/ab.sh, one box each): 4 lanes per chain with the likelihood's state in LDS (253 registers, nothing spilled: configs[3]
 // 1.92-2.00 -> 1.84 ms per step) and 16 lanes per chain (256 registers, 16 spilled: configs[4] +3-5 %).  Other lane counts keep
 // one wave per SIMD (8 lanes per chain would spill 31 registers; unmeasured).
-template <int LPC>
-constexpr bool dopri5_two_waves() { return SEPAIHRD_ARITH_FMA != 0 && ((LPC == 4 && SEPAIHRD_LL_STATE_IN_LDS != 0) || LPC == 16); }
+// (dopri5_two_waves<LPC>() is defined in front of the kernel, which asks it too)
 
 template <int LPC, int SOLVER>
 inline bool split_pays(size_t blocks) {
@@ -1220,7 +1229,7 @@ inline bool split_pays(size_t blocks) {
 #endif
     if (!(SEPAIHRD_ARITH_FMA != 0 && SOLVER == 0)) return false;
     // from two waves per SIMD on the tolerance build's 4-age Dopri5 integrator keeps its logs inline at 256 registers (LL_IN_LDS)
-    if (dopri5_two_waves<LPC>() && blocks >= (size_t)2 * 1024) return false;
+    if (dopri5_two_waves<LPC>()) return false;  // (above 1024 workgroups: the two-wave inline form)
     static const bool second_wave = [] {
         hipFuncAttributes attr;
         return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>)) == hipSuccess &&
@@ -1297,8 +1306,8 @@ int launch_one(const DevProblem& pb, const double* d_theta, int B, const EvalOut
     if (split_pays<LPC, SOLVER>((size_t)blocks) || out.force_split)
         return launch_wps<LPC, SOLVER, 1, false>(pb, d_theta, blocks, B, out, stream);
     if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || dopri5_two_waves<LPC>()))) {
-        // two waves per SIMD only pay when there are two waves for every SIMD
-        if (blocks >= 2 * 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
+        // the two-wave form as soon as some SIMD has to hold two waves (its one-wave sibling cannot: one_wave_per_simd_only)
+        if (blocks > 1024) return launch_wps<LPC, SOLVER, 2, true>(pb, d_theta, blocks, B, out, stream);
     }
     return launch_wps<LPC, SOLVER, 1, true>(pb, d_theta, blocks, B, out, stream);
 }
@@ -1343,7 +1352,7 @@ int info_one(const DevProblem& pb, int batch, LaunchInfo* info, const char* name
     if (split_pays<LPC, SOLVER>(blocks))
         return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, false>, pb, LPC, info, name, LL_FORM_SEPARATE_PASS);
     if constexpr (SOLVER == 1 || (SEPAIHRD_ARITH_FMA && (SEPAIHRD_DOPRI5_WPS2 || dopri5_two_waves<LPC>()))) {
-        if (blocks >= 2 * 1024) return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 2, true>, pb, LPC, info, name, LL_FORM_INLINE);
+        if (blocks > 1024) return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 2, true>, pb, LPC, info, name, LL_FORM_INLINE);
     }
     return info_of(&sepaihrd_eval_kernel<LPC, SOLVER, SEPAIHRD_ARITH_FMA, 1, true>, pb, LPC, info, name, LL_FORM_INLINE);
 }
