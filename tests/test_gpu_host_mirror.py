@@ -993,3 +993,26 @@ def test_draws_queued_behind_the_evaluation_give_the_overlapped_result(mm, shipp
         for k in ("accept_trace", "accepted", "best_value", "best", "final_scale", "samples", "sample_values", "final_cov"):
             assert np.array_equal(r[k], ref[k]), (key, k)
     assert 0 < ref["accept_trace"].mean() < 1
+
+
+def test_forms_that_serve_one_wave_per_simd_cannot_be_paired_on_a_simd(mm, synth400):
+    """Up to 1024 one-wave workgroups a batch means at most one integrator wave per SIMD -- but only if two of them do not FIT a
+    SIMD: behind any kernel that touched tens of MB the workgroup dispatcher pairs up what fits while other SIMDs stay empty
+    (round 4: 16 384 chains 0.95 -> 1.46 ms; tools/probe_dispatch_placement.py, profiles/r04_dispatch_placement_probe.txt).
+    The forms launched for such batches therefore allocate more than half a SIMD's 512 registers (the inline Dopri5 kernel needs
+    them; the others declare an accumulation register they never touch), from 1025 workgroups on the two-wave sibling takes
+    over, and the 16-lane form asks for half a CU's LDS (one workgroup per CU)."""
+    for solver in (mm.SOLVER_DOPRI5, mm.SOLVER_CASH_KARP54):
+        hip = mm.HipObjective(synth400.with_(arith=mm.ARITH_FMA, solver=solver))
+        for batch in (6000, 8192, 12288, 16384):        # 375 .. 1024 one-wave workgroups
+            info = hip.kernel_info(batch)
+            assert info["lanes_per_chain"] == 4 and info["vgprs"] > 256, (solver, batch, info)
+        info = hip.kernel_info(16384)
+        if solver == mm.SOLVER_DOPRI5:
+            assert info["likelihood_form"] == 0, info          # inline: nothing parked between half and one wave per SIMD
+        for batch in (16400, 24576, 32768):              # some SIMD has to hold two waves: the two-wave form, which shares by design
+            info = hip.kernel_info(batch)
+            assert info["vgprs"] <= 256 and info["max_blocks_per_cu"] >= 8 and info["likelihood_form"] == 0, (solver, batch, info)
+        info = hip.kernel_info(4096)                     # the 16-lane form: one 8-wave workgroup per CU
+        assert info["lanes_per_chain"] == 16 and info["max_blocks_per_cu"] == 1 and info["lds_bytes"] >= 80 * 1024, info
+        hip.close()
