@@ -135,6 +135,11 @@ template <int LPC, int SOLVER, int WPS>
 __global__ __launch_bounds__(WAVE, WPS) void sepaihrd_eval_f32_kernel(const DevProblem pb, const double* __restrict__ theta,
                                                                      const int B, const EvalOutputs out) {
     constexpr int CPW = WAVE / LPC;
+    // WPS = 1: the build launched for at most one wave per SIMD (<= 1024 workgroups).  It declares an accumulation register
+    // it never touches, which takes its allocation past 256 registers: two of its waves do not fit a SIMD and the
+    // dispatcher cannot pair them up while other SIMDs idle (4096 chains of the 16-age problem behind a 64-MB kernel:
+    // 2.04 -> 3.04 ms with the two-wave build; sepaihrd_kernels.hip one_wave_per_simd_only, tools/probe_dispatch_placement.py)
+    if constexpr (WPS == 1) asm volatile("" ::: "a127");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // no output grid here (the next grid time rides in the observation records): half the fp64 kernels' LDS, so that
     // LDS does not cap the waves per CU below what the registers allow
@@ -534,8 +539,12 @@ int launch_f32_one(const DevProblem& pb, const double* d_theta, int B, const Eva
     constexpr int CPW = WAVE / LPC;
     const int blocks = (B + CPW - 1) / CPW;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((sepaihrd_eval_f32_kernel<LPC, SOLVER, f32_waves_per_simd<LPC>()>), dim3(blocks), dim3(WAVE),
-                       f32_lds_bytes(pb), static_cast<hipStream_t>(stream), pb, d_theta, B, out);
+    if (blocks <= 1024)
+        hipLaunchKernelGGL((sepaihrd_eval_f32_kernel<LPC, SOLVER, 1>), dim3(blocks), dim3(WAVE), f32_lds_bytes(pb), static_cast<hipStream_t>(stream), pb,
+                           d_theta, B, out);
+    else
+        hipLaunchKernelGGL((sepaihrd_eval_f32_kernel<LPC, SOLVER, f32_waves_per_simd<LPC>()>), dim3(blocks), dim3(WAVE),
+                           f32_lds_bytes(pb), static_cast<hipStream_t>(stream), pb, d_theta, B, out);
     if (out.ev_after_integrator) (void)hipEventRecord(static_cast<hipEvent_t>(out.ev_after_integrator), static_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

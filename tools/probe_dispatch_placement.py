@@ -9,9 +9,10 @@ import mmid_amd_loader
 mm = mmid_amd_loader.load()
 from mmid_amd import draws, workloads
 dev = torch.device("cuda", 0)
-pb = workloads.build("c1", os.path.join(ROOT, "tests", "golden"), hip_factory=lambda q: mm.HipObjective(q))
+pb = workloads.build(os.environ.get("PROBE_WORKLOAD", "c1"), os.path.join(ROOT, "tests", "golden"), hip_factory=lambda q: mm.HipObjective(q))
 pb.arith = mm.ARITH_STRICT if os.environ.get("PROBE_ARITH") == "strict" else mm.ARITH_FMA; pb.constraint_mode = mm.CONSTRAINT_REFLECT
 if os.environ.get("PROBE_SOLVER") == "cashkarp": pb.solver = mm.SOLVER_CASH_KARP54
+if os.environ.get("PROBE_PRECISION") == "f32": pb.precision = mm.PRECISION_F32
 B = int(os.environ.get("PROBE_CHAINS", "16384"))
 theta = torch.from_numpy(draws.jitter_draws(pb, 1, B)).to(dev)
 d_ll = torch.empty(B, dtype=torch.float64, device=dev); d_st = torch.empty(B, dtype=torch.int32, device=dev)
