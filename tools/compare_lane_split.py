@@ -16,9 +16,12 @@ def evaluate(mm, args, form, fma_lib_wave_chain=False):
 
     def run(q, th):
         hip = mm.HipObjective(q)
-        if form is not None:
-            hip.set_integrator_form(form)
-        return hip.eval_batch(th, want_traj=True)
+        try:
+            if form is not None:
+                hip.set_integrator_form(form)
+            return hip.eval_batch(th, want_traj=True)
+        finally:
+            hip.close()  # not left to the interpreter's shutdown: two dozen contexts torn down in arbitrary order beside a second process on the card
 
     rng = np.random.default_rng(1)
     if args.fuzz:
@@ -79,7 +82,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.out:
         child(a)
-        sys.exit(0)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)  # the arrays are on disk and every context is closed: nothing for the runtime's exit handlers to race over
     sys.path.insert(0, ROOT)
     import mmid_amd_loader
     mm = mmid_amd_loader.load()
