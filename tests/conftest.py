@@ -13,6 +13,14 @@ import mmid_amd_loader  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Contexts the tests left to the garbage collector are destroyed HERE, while the HIP runtime is still whole, instead of in
+    whatever order the interpreter tears modules down at exit (a runtime that has begun to unload can crash the process after
+    the last test has passed and turn a green run into a non-zero exit code)."""
+    import gc
+    gc.collect()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
