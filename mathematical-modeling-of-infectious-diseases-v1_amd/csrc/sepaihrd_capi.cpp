@@ -1083,7 +1083,7 @@ sepaihrd_mh* sepaihrd_mh_create(sepaihrd_ctx* ctx, const sepaihrd_mh_config* cfg
     const size_t CP = (size_t)C * P, CPP = CP * P;
     {
         // say what the state costs before allocating instead of failing somewhere inside
-        const double need = (double)CP * ((double)window + (double)n_store) * 8.0 + 3.0 * (double)CPP * 8.0 + 8.0 * (double)CP * 8.0;
+        const double need = (double)CP * ((double)window + (double)n_store) * 8.0 + 3.0 * (double)CPP * 8.0 + 10.0 * (double)CP * 8.0;  // ... + the C*P arrays (state, proposal, means, sums, normals, L z)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b) {
             char msg[320];
